@@ -1,0 +1,114 @@
+"""ctypes binding of the C ABI declared in include/audiblelight_hip.h.
+
+The shared library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is
+no fallback of any kind: if the library is missing or a call fails, an exception is raised.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
+
+AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
+MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
+
+# numpy mirrors of al_event / al_stream (the tables are built on the host and copied to HBM)
+EVENT_DTYPE = np.dtype([
+    ("audio_off", "<i8"), ("out_off", "<i8"), ("len", "<i4"), ("valid_len", "<i4"), ("n_blocks", "<i4"),
+    ("stream0", "<i4"), ("n_streams", "<i4"), ("yspec_base", "<i4"), ("part_base", "<i4"),
+    ("snr", "<f4"), ("ref_db", "<f4"), ("reserved", "<i4")], align=True)
+STREAM_DTYPE = np.dtype([
+    ("event", "<i4"), ("emitter", "<i4"), ("j_lo", "<i4"), ("n_j", "<i4"), ("xspec_base", "<i4"),
+    ("w_off", "<i4"), ("w_len", "<i4"), ("gain", "<f4")], align=True)
+assert EVENT_DTYPE.itemsize == 56 and STREAM_DTYPE.itemsize == 32
+
+
+class AlBatch(ct.Structure):
+    _fields_ = [
+        ("log2_block", ct.c_int32), ("n_capsules", ct.c_int32), ("n_events", ct.c_int32), ("n_streams", ct.c_int32),
+        ("n_emitters", ct.c_int32), ("ir_len", ct.c_int32), ("ir_stride_c", ct.c_int64), ("ir_stride_n", ct.c_int64),
+        ("n_partitions", ct.c_int32), ("max_blocks", ct.c_int32), ("max_nj", ct.c_int32), ("hop", ct.c_int32),
+        ("twiddle", ct.c_void_p), ("audio", ct.c_void_p), ("ir", ct.c_void_p), ("wtab", ct.c_void_p),
+        ("events", ct.c_void_p), ("streams", ct.c_void_p),
+        ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),
+        ("yspec", ct.c_void_p), ("spatial", ct.c_void_p), ("partials", ct.c_void_p), ("event_stats", ct.c_void_p),
+        ("event_scale", ct.c_void_p),
+    ]
+
+
+class AlMix(ct.Structure):
+    _fields_ = [
+        ("n_capsules", ct.c_int32), ("n_samples", ct.c_int32), ("tile", ct.c_int32), ("n_tiles", ct.c_int32),
+        ("accumulate", ct.c_int32), ("reserved", ct.c_int32),
+        ("tile_ptr", ct.c_void_p), ("tile_events", ct.c_void_p), ("slot_src", ct.c_void_p), ("slot_len", ct.c_void_p),
+        ("slot_start", ct.c_void_p), ("slot_count", ct.c_void_p), ("slot_rows", ct.c_void_p), ("slot_event", ct.c_void_p),
+        ("spatial", ct.c_void_p), ("event_scale", ct.c_void_p), ("scene", ct.c_void_p),
+    ]
+
+
+class HipError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+
+# every symbol include/audiblelight_hip.h declares: (restype, argtypes)
+_P, _S = ct.c_void_p, ct.c_void_p
+SYMBOLS = {
+    "al_last_error": (ct.c_char_p, []),
+    "al_abi_version": (ct.c_int, []),
+    "al_twiddle_bytes": (ct.c_int64, [ct.c_int]),
+    "al_twiddle_init": (ct.c_int, [_P, ct.c_int, _S]),
+    "al_ir_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_emitter_gains": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_signal_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_render_batch": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_mixdown": (ct.c_int, [ct.POINTER(AlMix), _S]),
+    "al_scale_rows": (ct.c_int, [_P, ct.c_int64, _P, _S]),
+    "al_axpy": (ct.c_int, [_P, _P, _P, ct.c_int64, _S]),
+    "al_row_stats": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _P, _S]),
+    "al_row_stats_partials": (ct.c_int64, [ct.c_int32, ct.c_int64]),
+}
+
+
+class Library:
+    """Loaded C-ABI library; ``call(name, *args)`` raises HipError on a negative status."""
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or os.environ.get("AUDIBLELIGHT_HIP_LIB") or DEFAULT_LIB
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"audiblelight_amd: HIP extension not found at {path}. Build it with "
+                f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                f"There is no CPU fallback.")
+        self.path = path
+        self._dll = ct.CDLL(path)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(self._dll, name)  # AttributeError if the library does not export it
+            fn.restype, fn.argtypes = res, args
+            setattr(self, "_" + name, fn)
+
+    def last_error(self) -> str:
+        return (self._al_last_error() or b"").decode()
+
+    def call(self, name: str, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if isinstance(rc, int) and rc < 0 and SYMBOLS[name][0] is ct.c_int:
+            raise HipError(f"{name} failed ({rc}): {self.last_error()}")
+        return rc
+
+
+_default: Optional[Library] = None
+
+
+def get_library() -> Library:
+    global _default
+    if _default is None:
+        _default = Library()
+    return _default

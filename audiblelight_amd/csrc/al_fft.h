@@ -1,0 +1,268 @@
+// In-LDS Stockham FFT for gfx950 (CDNA4): the per-block transform of the partitioned
+// overlap-save convolution (DESIGN.md "Kernels").
+//
+// Geometry: a transform of M = 2^LOG2M complex points is done by one workgroup of T = M/16
+// threads (M = 8192 -> 512 threads = 8 wave64).  Every thread owns 16 complex values per pass,
+// always the LDS slots  tid + T*m, m = 0..15  on the read side (so reads are 512 contiguous
+// bytes per wave: conflict-free ds_read_b64), and scatters its butterfly outputs in Stockham
+// auto-sort order on the write side.  The LDS image is padded by one float2 per 16 so the
+// stride-16 scatter of the first pass and the 16-wide runs of the second land on distinct
+// banks (ds_write_b64 is serviced 16 lanes at a time over 32 dword banks).
+// Passes are radix 16 (4x4 in registers) with one final radix 2/4/8 pass when LOG2M is not a
+// multiple of 4.  A pass is: read 16 -> twiddle -> butterflies -> barrier -> write 16 -> barrier,
+// in place (all reads of a pass complete before any write).
+//
+// Twiddles: one table tw[k] = exp(-i*pi*k/M), k < M (the 2M-th roots over half a turn, made
+// in float64 by al_twiddle_init).  A pass loads one base factor per butterfly and derives the
+// other powers by at most four complex products.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace al {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));
+}
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+// a += b * c
+__device__ __forceinline__ void cfma(float2 &a, float2 b, float2 c) {
+  a.x = fmaf(b.x, c.x, a.x);
+  a.x = fmaf(-b.y, c.y, a.x);
+  a.y = fmaf(b.x, c.y, a.y);
+  a.y = fmaf(b.y, c.x, a.y);
+}
+// multiply by DIR*i  (DIR = -1 forward transform, +1 inverse)
+template <int DIR>
+__device__ __forceinline__ float2 rot90(float2 a) {
+  return DIR < 0 ? make_float2(a.y, -a.x) : make_float2(-a.y, a.x);
+}
+
+constexpr int lds_pad(int i) { return i + (i >> 4); }
+constexpr int fft_threads(int log2m) { return (1 << log2m) / 16; }
+constexpr int fft_lds_elems(int log2m) { return lds_pad(1 << log2m); }
+constexpr int fft_npasses(int log2m) { return (log2m + 3) / 4; }
+constexpr int fft_radix(int log2m, int pass) { return (log2m - 4 * pass) >= 4 ? 16 : (1 << (log2m - 4 * pass)); }
+
+template <int DIR>
+__device__ __forceinline__ void bfly2(float2 &a, float2 &b) {
+  float2 t = csub(a, b);
+  a = cadd(a, b);
+  b = t;
+}
+
+template <int DIR>
+__device__ __forceinline__ void bfly4(float2 &a0, float2 &a1, float2 &a2, float2 &a3) {
+  float2 t0 = cadd(a0, a2), t1 = csub(a0, a2), t2 = cadd(a1, a3), t3 = rot90<DIR>(csub(a1, a3));
+  a0 = cadd(t0, t2);
+  a1 = cadd(t1, t3);
+  a2 = csub(t0, t2);
+  a3 = csub(t1, t3);
+}
+
+// x[0..7] natural order in, X[0..7] natural order out.
+template <int DIR>
+__device__ __forceinline__ void bfly8(float2 (&x)[8]) {
+  constexpr float H = 0.70710678118654752440f;
+  bfly4<DIR>(x[0], x[2], x[4], x[6]);  // even samples  -> A0[k1] at x[0],x[2],x[4],x[6]
+  bfly4<DIR>(x[1], x[3], x[5], x[7]);  // odd samples   -> A1[k1] at x[1],x[3],x[5],x[7]
+  // A1[k1] *= w8^(k1), w8 = exp(DIR * 2*pi*i/8)
+  float2 b1 = x[3], b3 = x[7];
+  x[3] = make_float2(H * (b1.x - DIR * b1.y), H * (b1.y + DIR * b1.x));
+  x[5] = rot90<DIR>(x[5]);
+  x[7] = make_float2(H * (-b3.x - DIR * b3.y), H * (-b3.y + DIR * b3.x));
+  float2 a0 = x[0], a1 = x[2], a2 = x[4], a3 = x[6];
+  float2 c0 = x[1], c1 = x[3], c2 = x[5], c3 = x[7];
+  x[0] = cadd(a0, c0); x[4] = csub(a0, c0);
+  x[1] = cadd(a1, c1); x[5] = csub(a1, c1);
+  x[2] = cadd(a2, c2); x[6] = csub(a2, c2);
+  x[3] = cadd(a3, c3); x[7] = csub(a3, c3);
+}
+
+// x[0..15] natural order in; X[k] ends up at x[4*(k%4) + k/4].
+template <int DIR>
+__device__ __forceinline__ void bfly16(float2 (&x)[16]) {
+  constexpr float C1 = 0.92387953251128675613f, S1 = 0.38268343236508977173f, H = 0.70710678118654752440f;
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) bfly4<DIR>(x[n2], x[4 + n2], x[8 + n2], x[12 + n2]);
+  // now x[4*k1 + n2] = A[n2][k1]; multiply by w16^(n2*k1), w16 = exp(DIR*2*pi*i/16)
+  const float2 w1 = make_float2(C1, DIR * S1), w2 = make_float2(H, DIR * H), w3 = make_float2(S1, DIR * C1);
+  const float2 w6 = make_float2(-H, DIR * H), w9 = make_float2(-C1, -DIR * S1);
+  x[5] = cmul(x[5], w1);   // k1=1,n2=1
+  x[6] = cmul(x[6], w2);   // k1=1,n2=2
+  x[7] = cmul(x[7], w3);   // k1=1,n2=3
+  x[9] = cmul(x[9], w2);   // k1=2,n2=1
+  x[10] = rot90<DIR>(x[10]);  // k1=2,n2=2 : w4
+  x[11] = cmul(x[11], w6);  // k1=2,n2=3
+  x[13] = cmul(x[13], w3);  // k1=3,n2=1
+  x[14] = cmul(x[14], w6);  // k1=3,n2=2
+  x[15] = cmul(x[15], w9);  // k1=3,n2=3
+#pragma unroll
+  for (int k1 = 0; k1 < 4; ++k1) bfly4<DIR>(x[4 * k1], x[4 * k1 + 1], x[4 * k1 + 2], x[4 * k1 + 3]);
+}
+
+// Twiddle powers w^1..w^(R-1) from two exact table entries (w^1, w^4): at most three
+// chained products per power.
+template <int R>
+__device__ __forceinline__ void twiddle_powers(float2 (&w)[16], float2 a, float2 b) {
+  w[1] = a;
+  if (R > 2) {
+    w[2] = cmul(a, a);
+    w[3] = cmul(w[2], a);
+  }
+  if (R > 4) {
+    w[4] = b;
+    w[5] = cmul(b, a);
+    w[6] = cmul(b, w[2]);
+    w[7] = cmul(b, w[3]);
+  }
+  if (R > 8) {
+    w[8] = cmul(b, b);
+    w[9] = cmul(w[8], a);
+    w[10] = cmul(w[8], w[2]);
+    w[11] = cmul(w[8], w[3]);
+    w[12] = cmul(w[8], b);
+    w[13] = cmul(w[12], a);
+    w[14] = cmul(w[12], w[2]);
+    w[15] = cmul(w[12], w[3]);
+  }
+}
+
+// One Stockham pass.  On entry (PASS == 0) v[m] holds in[tid + T*m]; later passes read those
+// slots from LDS themselves.  Outputs are scattered to LDS; the caller must have a barrier
+// between the last read of the LDS image and this call's writes when PASS == 0.
+//   butterfly j = tid + T*b reads in[j + r*M/R]      = v[b + r*NB]
+//   k = j mod NS;  factor exp(DIR*2*pi*i*r*k/(NS*R))
+//   out[(j - k)*R + k + q*NS] = X[q]
+template <int LOG2M, int DIR, int PASS>
+__device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  constexpr int R = fft_radix(LOG2M, PASS);
+  constexpr int NS = 1 << (4 * PASS);
+  constexpr int NB = 16 / R;
+  if (PASS > 0) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
+  }
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = tid + T * b;
+    const int k = j & (NS - 1);
+    if (PASS > 0) {
+      constexpr int STEP = 2 * M / (NS * R);
+      float2 a = tw[k * STEP];
+      float2 c = (R > 4) ? tw[4 * k * STEP] : a;
+      if (DIR > 0) {
+        a.y = -a.y;
+        c.y = -c.y;
+      }
+      float2 w[16];
+      twiddle_powers<R>(w, a, c);
+#pragma unroll
+      for (int r = 1; r < R; ++r) v[b + r * NB] = cmul(v[b + r * NB], w[r]);
+    }
+  }
+  // all LDS reads of this pass are done once every thread is here
+  if (PASS > 0) __syncthreads();
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int j = tid + T * b;
+    const int k = j & (NS - 1);
+    const int base = (j - k) * R + k;
+    if (R == 16) {
+      bfly16<DIR>(v);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s[lds_pad(base + q * NS)] = v[4 * (q & 3) + (q >> 2)];
+    } else if (R == 8) {
+      float2 x[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) x[r] = v[b + r * NB];
+      bfly8<DIR>(x);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) s[lds_pad(base + q * NS)] = x[q];
+    } else if (R == 4) {
+      float2 x0 = v[b], x1 = v[b + NB], x2 = v[b + 2 * NB], x3 = v[b + 3 * NB];
+      bfly4<DIR>(x0, x1, x2, x3);
+      s[lds_pad(base)] = x0;
+      s[lds_pad(base + NS)] = x1;
+      s[lds_pad(base + 2 * NS)] = x2;
+      s[lds_pad(base + 3 * NS)] = x3;
+    } else {
+      float2 x0 = v[b], x1 = v[b + NB];
+      bfly2<DIR>(x0, x1);
+      s[lds_pad(base)] = x0;
+      s[lds_pad(base + NS)] = x1;
+    }
+  }
+  __syncthreads();
+}
+
+template <int LOG2M, int DIR, int PASS>
+struct FftPasses {
+  static __device__ __forceinline__ void run(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
+    fft_pass<LOG2M, DIR, PASS>(v, s, tw, tid);
+    if constexpr (PASS + 1 < fft_npasses(LOG2M)) FftPasses<LOG2M, DIR, PASS + 1>::run(v, s, tw, tid);
+  }
+};
+
+// Complex FFT of the M values held as v[m] = in[tid + T*m]; the natural-order result is left
+// in the padded LDS image s[lds_pad(k)], visible to every thread (ends with a barrier).
+template <int LOG2M, int DIR>
+__device__ __forceinline__ void fft_regs_to_lds(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
+  FftPasses<LOG2M, DIR, 0>::run(v, s, tw, tid);
+}
+
+// ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)
+// Forward: Z = FFT_M(x[2n] + i x[2n+1]);  X[k] = E + w^k O,  X[M-k] = conj(E - w^k O),
+//   E = (Z[k] + conj Z[M-k])/2,  O = -i (Z[k] - conj Z[M-k])/2,  w = exp(-i*pi/M).
+// Spectrum layout: out[0] = (X[0], X[M]) (both real), out[k] = X[k] for 0 < k < M.
+template <int LOG2M>
+__device__ __forceinline__ void real_unpack_store(const float2 *s, const float2 *__restrict__ tw, int tid,
+                                                  float2 *__restrict__ out) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k == 0) {
+      const float2 z0 = s[0], zh = s[lds_pad(M / 2)];
+      out[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
+      out[M / 2] = cconj(zh);
+    } else {
+      const float2 zk = s[lds_pad(k)], zm = s[lds_pad(M - k)];
+      const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+      const float2 o = make_float2(d.y, -d.x);
+      const float2 wo = cmul(tw[k], o);
+      out[k] = cadd(e, wo);
+      out[M - k] = cconj(csub(e, wo));
+    }
+  }
+}
+
+// Inverse: from the packed spectrum Y build Z[k] = E + iO (scaled) into LDS, ready for the
+// inverse passes.  E = (Y[k] + conj Y[M-k])/2, O = conj(w^k) (Y[k] - conj Y[M-k])/2.
+template <int LOG2M>
+__device__ __forceinline__ void real_pack_load(const float2 *__restrict__ in, float2 *s,
+                                               const float2 *__restrict__ tw, int tid, float scale) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k == 0) {
+      const float2 y0 = in[0], yh = in[M / 2];
+      s[0] = make_float2(0.5f * scale * (y0.x + y0.y), 0.5f * scale * (y0.x - y0.y));
+      s[lds_pad(M / 2)] = make_float2(scale * yh.x, -scale * yh.y);
+    } else {
+      const float2 yk = in[k], ym = in[M - k];
+      const float hs = 0.5f * scale;
+      const float2 e = make_float2(hs * (yk.x + ym.x), hs * (yk.y - ym.y));
+      const float2 d = make_float2(hs * (yk.x - ym.x), hs * (yk.y + ym.y));
+      const float2 o = cmul(cconj(tw[k]), d);
+      s[lds_pad(k)] = make_float2(e.x - o.y, e.y + o.x);
+      s[lds_pad(M - k)] = make_float2(e.x + o.y, o.x - e.y);
+    }
+  }
+}
+
+}  // namespace al

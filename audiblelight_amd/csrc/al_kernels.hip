@@ -1,0 +1,557 @@
+// HIP kernels + C ABI of the MI355X synthesis path (gfx950 only).  See DESIGN.md for the data
+// layout and per-kernel rooflines, include/audiblelight_hip.h for the boundary.
+//
+// Pipeline per batch of events (uniformly partitioned overlap-save, block B = M = 2^LOG2M):
+//   k_ir_spectra      H[n,c,p]  = rFFT_2B([h[pB:(p+1)B], 0])        + partial sum of h^2
+//   k_emitter_gains   g[n]      = 1 / mean_c(||h_{n,c}|| + tiny)      (normalize_irs)
+//   k_signal_spectra  X[s,j]    = rFFT_2B(gain * env_s * a[(j-1)B:(j+1)B])
+//   k_spectral_mac    Y[e,c,k]  = sum_s g[n_s] sum_p X[s,k-p] * H[n_s,c,p]
+//   k_block_synthesis x[e,c,kB:(k+1)B] = irFFT_2B(Y[e,c,k])[B:2B]    + partial |x| statistics
+//   k_event_levels    scale[e]  = apply_snr o db_to_multiplier from sum|x|, max|x|
+//   k_mixdown         scene[c,t] (+)= sum_e scale[e] * x[e,c,t-start_e]
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/audiblelight_hip.h"
+#include "al_fft.h"
+
+namespace al {
+
+// ------------------------------------------------------------------ block-wide reductions
+// sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
+__device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,
+                                              int nthreads) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a_sum += __shfl_down(a_sum, off, 64);
+    b_max = fmaxf(b_max, __shfl_down(b_max, off, 64));
+    c_sum += __shfl_down(c_sum, off, 64);
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+    scratch[wave * 3 + 0] = a_sum;
+    scratch[wave * 3 + 1] = b_max;
+    scratch[wave * 3 + 2] = c_sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (nthreads + 63) >> 6;
+    for (int w = 1; w < nw; ++w) {
+      a_sum += scratch[w * 3 + 0];
+      b_max = fmaxf(b_max, scratch[w * 3 + 1]);
+      c_sum += scratch[w * 3 + 2];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ twiddle table
+__global__ void k_twiddle_init(float2 *tw, int m) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < m) {
+    double s, c;
+    sincospi(-(double)k / (double)m, &s, &c);
+    tw[k] = make_float2((float)c, (float)s);
+  }
+}
+
+// ------------------------------------------------------------------ 1. IR partition spectra
+template <int LOG2M>
+__global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  __shared__ float2 s[fft_lds_elems(LOG2M)];
+  __shared__ float red[48];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
+  const float *src = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)n * b.ir_stride_n + (int64_t)p * M;
+  const int remaining = b.ir_len - p * M;  // samples of this partition that exist (may exceed M)
+  float2 v[16];
+  float energy = 0.f;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {  // first half of the 2B window = the partition, second half zero
+    const int t = 2 * (tid + T * m);
+    float2 x = make_float2(0.f, 0.f);
+    if (t + 1 < remaining) {
+      x = *reinterpret_cast<const float2 *>(src + t);  // rows are 16-byte aligned, t is even
+    } else if (t < remaining) {
+      x.x = src[t];
+    }
+    v[m] = x;
+    energy = fmaf(x.x, x.x, energy);
+    energy = fmaf(x.y, x.y, energy);
+  }
+#pragma unroll
+  for (int m = 8; m < 16; ++m) v[m] = make_float2(0.f, 0.f);
+
+  fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
+  const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;
+  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + blk * M);
+
+  float mx = 0.f, z = 0.f;
+  block_reduce3(energy, mx, z, red, tid, T);
+  if (tid == 0) b.ir_energy[blk] = energy;
+}
+
+// ------------------------------------------------------------------ 2. emitter gains (normalize_irs)
+// one wave per emitter: g = 1 / mean_c( sqrt(sum_t h^2) + tiny(float64) )   (synthesize.py:425-428)
+__global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  double acc = 0.0;
+  for (int c = lane; c < b.n_capsules; c += 64) {
+    const float *e = b.ir_energy + ((int64_t)n * b.n_capsules + c) * b.n_partitions;
+    double sum = 0.0;
+    for (int p = 0; p < b.n_partitions; ++p) sum += (double)e[p];
+    acc += sqrt(sum) + 2.2250738585072014e-308;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) b.emitter_gain[n] = (float)((double)b.n_capsules / acc);
+}
+
+// ------------------------------------------------------------------ 3. signal block spectra
+// Cross-fade envelope of a moving stream at sample t:
+//   env(t) = W[q+1] * win(r) + W[q] * (1 - win(r)),  q = t / hop, r = t % hop, win(r) = sin^2(pi r / (2 hop))
+__device__ __forceinline__ float stream_envelope(const float *__restrict__ w, int w_len, int hop, int t) {
+  const int q = t / hop, r = t - q * hop;
+  const float sn = sinpif((float)r / (float)(2 * hop));
+  const float win = sn * sn;
+  const float w0 = q < w_len ? w[q] : 0.f;
+  const float w1 = q + 1 < w_len ? w[q + 1] : 0.f;
+  return fmaf(w1 - w0, win, w0);
+}
+
+template <int LOG2M>
+__global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch b) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  __shared__ float2 s[fft_lds_elems(LOG2M)];
+  const int tid = threadIdx.x;
+  const al_stream st = b.streams[blockIdx.y];
+  if ((int)blockIdx.x >= st.n_j) return;
+  const al_event ev = b.events[st.event];
+  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
+  const float *a = b.audio + ev.audio_off;
+  const float *w = st.w_off >= 0 ? b.wtab + st.w_off : nullptr;
+  const int j = st.j_lo + blockIdx.x;
+  const int t0 = (j - 1) * M;  // window [(j-1)B, (j+1)B)
+  float2 v[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    const int t = t0 + 2 * (tid + T * m);
+    float x0 = 0.f, x1 = 0.f;
+    if (t >= 0 && t < ev.len) x0 = a[t] * st.gain * (w ? stream_envelope(w, st.w_len, b.hop, t) : 1.f);
+    if (t + 1 >= 0 && t + 1 < ev.len) x1 = a[t + 1] * st.gain * (w ? stream_envelope(w, st.w_len, b.hop, t + 1) : 1.f);
+    v[m] = make_float2(x0, x1);
+  }
+  fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
+  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base + blockIdx.x) * M);
+}
+
+// ------------------------------------------------------------------ 4. frequency-domain accumulate
+// One thread per bin; KT output blocks accumulate in registers while the partitions stream by.
+template <int KT>
+__global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
+  const int M = 1 << b.log2_block;
+  const int f = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.y;
+  const al_event ev = b.events[blockIdx.z];
+  if (ev.n_streams <= 0) return;
+  const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
+  const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
+  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
+  const int K = ev.n_blocks, P = b.n_partitions;
+  const bool packed = (f == 0);  // bin 0 holds (DC, Nyquist): two independent real products
+
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    float2 acc[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) acc[kk] = make_float2(0.f, 0.f);
+    for (int l = 0; l < ev.n_streams; ++l) {
+      const al_stream st = b.streams[ev.stream0 + l];
+      const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
+      const int plo = max(0, k0 - jhi + 1), phi = min(P - 1, k0 + KT - 1 - jlo);
+      if (plo > phi) continue;
+      const float g = b.emitter_gain[st.emitter];
+      const float2 *hp = H + (((int64_t)st.emitter * b.n_capsules + c) * P) * M + f;
+      const float2 *xp = X + (int64_t)(st.xspec_base - jlo) * M + f;
+      for (int p = plo; p <= phi; ++p) {
+        float2 h = hp[(int64_t)p * M];
+        h.x *= g;
+        h.y *= g;
+#pragma unroll
+        for (int kk = 0; kk < KT; ++kk) {
+          const int j = k0 + kk - p;
+          if (j >= jlo && j < jhi) {
+            const float2 x = xp[(int64_t)j * M];
+            if (packed) {
+              acc[kk].x = fmaf(x.x, h.x, acc[kk].x);
+              acc[kk].y = fmaf(x.y, h.y, acc[kk].y);
+            } else {
+              cfma(acc[kk], x, h);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+      if (k0 + kk < K) Y[((int64_t)ev.yspec_base + (int64_t)c * K + k0 + kk) * M + f] = acc[kk];
+  }
+}
+
+// ------------------------------------------------------------------ 5. block synthesis
+template <int LOG2M>
+__global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch b) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  __shared__ float2 s[fft_lds_elems(LOG2M)];
+  __shared__ float red[48];
+  const int tid = threadIdx.x;
+  const int k = blockIdx.x, c = blockIdx.y;
+  const al_event ev = b.events[blockIdx.z];
+  if (k >= ev.n_blocks) return;
+  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
+  float *out = b.spatial + ev.out_off + (int64_t)c * ev.len;
+  const int tbase = k * M;
+  float asum = 0.f, amax = 0.f, bad = 0.f;
+
+  if (ev.n_streams <= 0) {
+    // no emitters: the clip is tiled over the capsules (synthesize.py:572-577)
+    const float gain = b.streams[ev.stream0].gain;
+    const float *a = b.audio + ev.audio_off;
+    for (int i = tid; i < M; i += T) {
+      const int t = tbase + i;
+      if (t < ev.len) {
+        const float x = a[t] * gain;
+        out[t] = x;
+        asum += fabsf(x);
+        amax = fmaxf(amax, fabsf(x));
+        bad += isfinite(x) ? 0.f : 1.f;
+      }
+    }
+  } else {
+    const float2 *y = reinterpret_cast<const float2 *>(b.yspec) + ((int64_t)ev.yspec_base + (int64_t)c * ev.n_blocks + k) * M;
+    real_pack_load<LOG2M>(y, s, tw, tid, 1.0f / (float)M);
+    __syncthreads();
+    float2 v[16];
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
+    __syncthreads();
+    fft_regs_to_lds<LOG2M, 1>(v, s, tw, tid);
+    // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B)
+    const bool pair_ok = (((ev.out_off + (int64_t)c * ev.len) & 1) == 0);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int i = tid + T * m;  // complex index inside the kept half
+      const float2 z = s[lds_pad(M / 2 + i)];
+      const int t = tbase + 2 * i;
+      const float x0 = t < ev.valid_len ? z.x : 0.f;
+      const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
+      if (t + 1 < ev.len) {
+        if (pair_ok) {
+          *reinterpret_cast<float2 *>(out + t) = make_float2(x0, x1);
+        } else {
+          out[t] = x0;
+          out[t + 1] = x1;
+        }
+      } else if (t < ev.len) {
+        out[t] = x0;
+      }
+      if (t < ev.len) {
+        asum += fabsf(x0);
+        amax = fmaxf(amax, fabsf(x0));
+        bad += isfinite(x0) ? 0.f : 1.f;
+      }
+      if (t + 1 < ev.len) {
+        asum += fabsf(x1);
+        amax = fmaxf(amax, fabsf(x1));
+        bad += isfinite(x1) ? 0.f : 1.f;
+      }
+    }
+  }
+  block_reduce3(asum, amax, bad, red, tid, T);
+  if (tid == 0) {
+    float *pp = b.partials + 4 * ((int64_t)ev.part_base + (int64_t)c * ev.n_blocks + k);
+    pp[0] = asum;
+    pp[1] = amax;
+    pp[2] = bad;
+    pp[3] = 0.f;
+  }
+}
+
+// ------------------------------------------------------------------ 6. event levels
+// Composite of apply_snr (synthesize.py:40-49) and db_to_multiplier (synthesize.py:52-68) as chained
+// at synthesize.py:594-599, evaluated in float64 from the deterministic partial statistics.
+__global__ __launch_bounds__(64) void k_event_levels(al_batch b) {
+  const al_event ev = b.events[blockIdx.x];
+  const int lane = threadIdx.x;
+  const int n = b.n_capsules * ev.n_blocks;
+  const float *pp = b.partials + 4 * (int64_t)ev.part_base;
+  double sum = 0.0, bad = 0.0;
+  float mx = 0.f;
+  for (int i = lane; i < n; i += 64) {
+    sum += (double)pp[4 * i];
+    mx = fmaxf(mx, pp[4 * i + 1]);
+    bad += (double)pp[4 * i + 2];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    bad += __shfl_down(bad, off, 64);
+  }
+  if (lane == 0) {
+    const double snr = (double)ev.snr;
+    const double peak = fmax((double)mx, 1e-15);
+    const double s1 = snr / peak;                                   // apply_snr
+    const double mean_abs = fabs(s1) * sum / ((double)b.n_capsules * (double)ev.len);
+    const double s2 = pow(10.0, ((double)ev.ref_db + snr) / 20.0) / (mean_abs + 2.2250738585072014e-308);
+    double *o = b.event_stats + 4 * (int64_t)blockIdx.x;
+    o[0] = sum;
+    o[1] = (double)mx;
+    o[2] = bad;
+    o[3] = s2;
+    b.event_scale[blockIdx.x] = (float)(s1 * s2);
+  }
+}
+
+// ------------------------------------------------------------------ 7. mixdown
+__global__ __launch_bounds__(256) void k_mixdown(al_mix m) {
+  const int tile = blockIdx.x, c = blockIdx.y;
+  const int lo = m.tile_ptr[tile], hi = m.tile_ptr[tile + 1];
+  const int t_begin = tile * m.tile;
+  const int t_end = min(t_begin + m.tile, m.n_samples);
+  float *row = m.scene + (int64_t)c * m.n_samples;
+  for (int t = t_begin + threadIdx.x; t < t_end; t += 256) {
+    float acc = m.accumulate ? row[t] : 0.f;
+    for (int q = lo; q < hi; ++q) {
+      const int sl = m.tile_events[q];
+      const int rel = t - m.slot_start[sl];
+      if (c < m.slot_rows[sl] && rel >= 0 && rel < m.slot_count[sl]) {
+        const float x = m.spatial[m.slot_src[sl] + (int64_t)c * m.slot_len[sl] + rel];
+        acc = fmaf(m.event_scale[m.slot_event[sl]], x, acc);
+      }
+    }
+    row[t] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ helpers
+__global__ __launch_bounds__(256) void k_scale(float *x, int64_t n, const float *scale) {
+  const float s = *scale;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
+}
+
+__global__ __launch_bounds__(256) void k_axpy(float *y, const float *x, const float *a, int64_t n) {
+  const float s = *a;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    y[i] = fmaf(s, x[i], y[i]);
+}
+
+constexpr int ROW_CHUNK = 16384;  // samples per partial of k_row_stats
+
+__global__ __launch_bounds__(256) void k_row_stats(const float *x, int64_t cols, float *partials) {
+  __shared__ float red[48];
+  const int chunk = blockIdx.x, r = blockIdx.y;
+  const int64_t lo = (int64_t)chunk * ROW_CHUNK, hi = lo + ROW_CHUNK < cols ? lo + ROW_CHUNK : cols;
+  const float *row = x + (int64_t)r * cols;
+  float asum = 0.f, amax = 0.f, bad = 0.f;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = row[i];
+    asum += fabsf(v);
+    amax = fmaxf(amax, fabsf(v));
+    bad += isfinite(v) ? 0.f : 1.f;
+  }
+  block_reduce3(asum, amax, bad, red, threadIdx.x, 256);
+  if (threadIdx.x == 0) {
+    float *pp = partials + 4 * ((int64_t)r * gridDim.x + chunk);
+    pp[0] = asum;
+    pp[1] = amax;
+    pp[2] = bad;
+    pp[3] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_row_stats_final(const float *partials, int nchunks, double *out) {
+  const int r = blockIdx.x, lane = threadIdx.x;
+  const float *pp = partials + 4 * (int64_t)r * nchunks;
+  double sum = 0.0, bad = 0.0;
+  float mx = 0.f;
+  for (int i = lane; i < nchunks; i += 64) {
+    sum += (double)pp[4 * i];
+    mx = fmaxf(mx, pp[4 * i + 1]);
+    bad += (double)pp[4 * i + 2];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    sum += __shfl_down(sum, off, 64);
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    bad += __shfl_down(bad, off, 64);
+  }
+  if (lane == 0) {
+    out[4 * r + 0] = sum;
+    out[4 * r + 1] = (double)mx;
+    out[4 * r + 2] = bad;
+    out[4 * r + 3] = 0.0;
+  }
+}
+
+}  // namespace al
+
+// ====================================================================== C ABI
+namespace {
+thread_local char g_err[256] = "";
+
+int fail(int code, const char *msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+
+int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return AL_E_HIP;
+  }
+  return AL_OK;
+}
+
+int check_batch(const al_batch *b) {
+  if (!b) return fail(AL_E_BADARG, "null batch");
+  if (b->log2_block < AL_MIN_LOG2_BLOCK || b->log2_block > AL_MAX_LOG2_BLOCK)
+    return fail(AL_E_UNSUPPORTED, "log2_block must be in [10, 14]");
+  if (b->n_capsules <= 0 || b->n_events < 0 || b->n_streams < 0) return fail(AL_E_BADARG, "bad batch sizes");
+  if ((b->ir_stride_c & 3) || (b->ir_stride_n & 3)) return fail(AL_E_BADARG, "IR strides must be multiples of 4 floats");
+  if (((uintptr_t)b->ir & 15) != 0) return fail(AL_E_BADARG, "IR base must be 16-byte aligned");
+  if (b->n_emitters > 0 && b->n_partitions != ((b->ir_len + (1 << b->log2_block) - 1) >> b->log2_block))
+    return fail(AL_E_BADARG, "n_partitions != ceil(ir_len / B)");
+  if (b->hop <= 0) return fail(AL_E_BADARG, "hop must be positive");
+  return AL_OK;
+}
+
+#define AL_DISPATCH_LOG2(log2, CALL)            \
+  switch (log2) {                               \
+    case 10: { constexpr int L = 10; CALL; } break; \
+    case 11: { constexpr int L = 11; CALL; } break; \
+    case 12: { constexpr int L = 12; CALL; } break; \
+    case 13: { constexpr int L = 13; CALL; } break; \
+    case 14: { constexpr int L = 14; CALL; } break; \
+    default: return fail(AL_E_UNSUPPORTED, "unsupported block size"); \
+  }
+}  // namespace
+
+extern "C" {
+
+const char *al_last_error(void) { return g_err; }
+int al_abi_version(void) { return 1; }
+
+int64_t al_twiddle_bytes(int log2_block) {
+  if (log2_block < AL_MIN_LOG2_BLOCK || log2_block > AL_MAX_LOG2_BLOCK) return -1;
+  return (int64_t)sizeof(float) * 2 * ((int64_t)1 << log2_block);
+}
+
+int al_twiddle_init(float *twiddle, int log2_block, al_stream_t stream) {
+  if (!twiddle || al_twiddle_bytes(log2_block) < 0) return fail(AL_E_BADARG, "bad twiddle arguments");
+  const int m = 1 << log2_block;
+  hipLaunchKernelGGL(al::k_twiddle_init, dim3((m + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float2 *>(twiddle), m);
+  return check_launch("k_twiddle_init");
+}
+
+int al_ir_spectra(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_emitters <= 0) return AL_OK;
+  const dim3 grid(b->n_partitions, b->n_capsules, b->n_emitters);
+  AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_ir_spectra<L>), grid, dim3(al::fft_threads(L)), 0,
+                                                      (hipStream_t)stream, *b));
+  return check_launch("k_ir_spectra");
+}
+
+int al_emitter_gains(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_emitters <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_emitter_gains, dim3(b->n_emitters), dim3(64), 0, (hipStream_t)stream, *b);
+  return check_launch("k_emitter_gains");
+}
+
+int al_signal_spectra(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_streams <= 0 || b->max_nj <= 0) return AL_OK;
+  const dim3 grid(b->max_nj, b->n_streams);
+  AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_signal_spectra<L>), grid, dim3(al::fft_threads(L)), 0,
+                                                      (hipStream_t)stream, *b));
+  return check_launch("k_signal_spectra");
+}
+
+int al_spectral_mac(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_events <= 0 || b->n_emitters <= 0) return AL_OK;
+  const dim3 grid((1 << b->log2_block) / 256, b->n_capsules, b->n_events);
+  hipLaunchKernelGGL((al::k_spectral_mac<8>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  return check_launch("k_spectral_mac");
+}
+
+int al_block_synthesis(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_events <= 0 || b->max_blocks <= 0) return AL_OK;
+  const dim3 grid(b->max_blocks, b->n_capsules, b->n_events);
+  AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_block_synthesis<L>), grid, dim3(al::fft_threads(L)), 0,
+                                                      (hipStream_t)stream, *b));
+  return check_launch("k_block_synthesis");
+}
+
+int al_event_levels(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_events <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_event_levels, dim3(b->n_events), dim3(64), 0, (hipStream_t)stream, *b);
+  return check_launch("k_event_levels");
+}
+
+int al_render_batch(const al_batch *b, al_stream_t stream) {
+  int rc;
+  if ((rc = al_ir_spectra(b, stream))) return rc;
+  if ((rc = al_emitter_gains(b, stream))) return rc;
+  if ((rc = al_signal_spectra(b, stream))) return rc;
+  if ((rc = al_spectral_mac(b, stream))) return rc;
+  if ((rc = al_block_synthesis(b, stream))) return rc;
+  return al_event_levels(b, stream);
+}
+
+int al_mixdown(const al_mix *m, al_stream_t stream) {
+  if (!m || m->n_capsules <= 0 || m->n_samples <= 0 || m->tile <= 0) return fail(AL_E_BADARG, "bad mixdown arguments");
+  if (m->n_tiles != (m->n_samples + m->tile - 1) / m->tile) return fail(AL_E_BADARG, "n_tiles != ceil(n_samples / tile)");
+  hipLaunchKernelGGL(al::k_mixdown, dim3(m->n_tiles, m->n_capsules), dim3(256), 0, (hipStream_t)stream, *m);
+  return check_launch("k_mixdown");
+}
+
+int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream) {
+  if (!x || !scale || n < 0) return fail(AL_E_BADARG, "bad scale arguments");
+  if (n == 0) return AL_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_scale, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+  return check_launch("k_scale");
+}
+
+int al_axpy(float *y, const float *x, const float *a_dev, int64_t n, al_stream_t stream) {
+  if (!x || !y || !a_dev || n < 0) return fail(AL_E_BADARG, "bad axpy arguments");
+  if (n == 0) return AL_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_axpy, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, y, x, a_dev, n);
+  return check_launch("k_axpy");
+}
+
+int64_t al_row_stats_partials(int32_t rows, int64_t cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return 4 * (int64_t)rows * ((cols + al::ROW_CHUNK - 1) / al::ROW_CHUNK);
+}
+
+int al_row_stats(const float *x, int32_t rows, int64_t cols, float *partials, double *out, al_stream_t stream) {
+  if (!x || !partials || !out || rows <= 0 || cols <= 0) return fail(AL_E_BADARG, "bad row_stats arguments");
+  const int nchunks = (int)((cols + al::ROW_CHUNK - 1) / al::ROW_CHUNK);
+  hipLaunchKernelGGL(al::k_row_stats, dim3(nchunks, rows), dim3(256), 0, (hipStream_t)stream, x, cols, partials);
+  if (int rc = check_launch("k_row_stats")) return rc;
+  hipLaunchKernelGGL(al::k_row_stats_final, dim3(rows), dim3(64), 0, (hipStream_t)stream, partials, nchunks, out);
+  return check_launch("k_row_stats_final");
+}
+
+}  // extern "C"

@@ -1,0 +1,187 @@
+"""Device orchestration of the HIP synthesis path: buffers, table upload, kernel launches.
+
+PyTorch is used for plumbing only (HBM allocation, H2D/D2H copies, the current HIP stream);
+all arithmetic happens in the kernels behind the C ABI (include/audiblelight_hip.h).
+"""
+from __future__ import annotations
+
+import ctypes as ct
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _hip
+from .plan import BatchPlan, MixPlan
+
+
+# ----------------------------------------------------------------------------- memory providers
+class TorchMemory:
+    """HBM through torch (ROCm).  Raises if no GPU is visible: there is no CPU path."""
+
+    def __init__(self, device=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("audiblelight_amd needs a ROCm GPU (torch.cuda.is_available() is False); no CPU fallback")
+        self.torch = torch
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+
+    def stream(self):
+        return ct.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, n: int, dtype=np.float32):
+        return self.torch.empty(max(int(n), 1), dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+
+    def zeros(self, n: int, dtype=np.float32):
+        return self.torch.zeros(max(int(n), 1), dtype=getattr(self.torch, np.dtype(dtype).name), device=self.device)
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.fields is not None:  # structured table -> raw bytes
+            arr = arr.view(np.uint8)
+        return self.torch.from_numpy(arr).to(self.device, non_blocking=False)
+
+    def ptr(self, buf) -> int:
+        return buf.data_ptr()
+
+    def download(self, buf) -> np.ndarray:
+        return buf.cpu().numpy()
+
+    def synchronize(self):
+        self.torch.cuda.synchronize(self.device)
+
+
+# ----------------------------------------------------------------------------- results
+@dataclass
+class RenderResult:
+    plan: BatchPlan
+    memory: object
+    lib: _hip.Library
+    spatial: object        # device: per event (C, len) UNSCALED convolution
+    event_scale: object    # device float32[E]
+    event_stats: object    # device float64[E, 4]: sum|x|, max|x|, non-finite count, db multiplier
+    emitter_gain: object   # device float32[n_emitters]
+    keep: tuple = ()       # buffers that must outlive the launches
+
+    def scales(self) -> np.ndarray:
+        return self.memory.download(self.event_scale)[: len(self.plan.events)].astype(np.float64)
+
+    def stats(self) -> np.ndarray:
+        return self.memory.download(self.event_stats)[: 4 * len(self.plan.events)].reshape(-1, 4)
+
+    def check_finite(self) -> None:
+        bad = np.flatnonzero(self.stats()[:, 2] > 0)
+        if len(bad):
+            raise ValueError(f"Audio buffer is not finite everywhere (events {bad.tolist()})")
+
+    def raw_spatial(self, i: int) -> np.ndarray:
+        ev = self.plan.events[i]
+        n = self.plan.n_capsules * int(ev["len"])
+        flat = self.memory.download(self.spatial[int(ev["out_off"]): int(ev["out_off"]) + n])
+        return flat.reshape(self.plan.n_capsules, int(ev["len"]))
+
+    def spatial_audio(self, i: int) -> np.ndarray:
+        """event.spatial_audio[mic]: the scaled (C, La) render (synthesize.py:599,606)."""
+        return self.raw_spatial(i).astype(np.float64) * self.scales()[i]
+
+
+class Renderer:
+    """Launches the batch pipeline of include/audiblelight_hip.h on one GPU."""
+
+    def __init__(self, lib: Optional[_hip.Library] = None, memory=None):
+        self.lib = lib or _hip.get_library()
+        self.mem = memory or TorchMemory()
+        self._twiddles: Dict[int, object] = {}
+
+    def twiddle(self, log2_block: int):
+        if log2_block not in self._twiddles:
+            nbytes = self.lib.call("al_twiddle_bytes", log2_block)
+            buf = self.mem.empty(nbytes // 4, np.float32)
+            self.lib.call("al_twiddle_init", self.mem.ptr(buf), log2_block, self.mem.stream())
+            self._twiddles[log2_block] = buf
+        return self._twiddles[log2_block]
+
+    # -- IR upload: (C, N, L) any float dtype -> float32 device tensor with 4-float aligned rows
+    def upload_irs(self, irs: np.ndarray):
+        c, n, l = irs.shape
+        lp = (l + 3) // 4 * 4
+        host = np.zeros((c, max(n, 1), lp), dtype=np.float32)
+        host[:, :n, :l] = irs
+        return self.mem.upload(host.reshape(-1)), (n * lp if n else lp, lp)
+
+    def pack_audio(self, plan: BatchPlan, clips: Sequence[np.ndarray]) -> np.ndarray:
+        host = np.zeros(plan.audio_floats, dtype=np.float32)
+        for off, clip in zip(plan.audio_offsets, clips):
+            host[off: off + len(clip)] = clip
+        return host
+
+    def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
+               stages: Optional[Sequence[str]] = None) -> RenderResult:
+        """Run stages 1-6 for one batch.  ``irs`` is a (C, N, L) ndarray or a device buffer
+        returned by upload_irs (then ``ir_strides`` = (stride_c, stride_n))."""
+        mem, lib = self.mem, self.lib
+        if isinstance(irs, np.ndarray):
+            irs, ir_strides = self.upload_irs(irs)
+        audio = mem.upload(self.pack_audio(plan, clips))
+        events = mem.upload(plan.events)
+        streams = mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE))
+        wtab = mem.upload(plan.wtab)
+        B = plan.block
+        ir_energy = mem.empty(plan.hspec_blocks)
+        gains = mem.empty(plan.n_emitters)
+        hspec = mem.empty(plan.hspec_blocks * B * 2)
+        xspec = mem.empty(plan.xspec_blocks * B * 2)
+        yspec = mem.empty(plan.yspec_blocks * B * 2)
+        spatial = mem.empty(plan.spatial_floats)
+        partials = mem.empty(plan.n_partials * 4)
+        stats = mem.empty(len(plan.events) * 4, np.float64)
+        scale = mem.empty(len(plan.events))
+        tw = self.twiddle(plan.log2_block)
+        p = mem.ptr
+        b = _hip.AlBatch(
+            log2_block=plan.log2_block, n_capsules=plan.n_capsules, n_events=len(plan.events),
+            n_streams=len(plan.streams), n_emitters=plan.n_emitters, ir_len=plan.ir_len,
+            ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1], n_partitions=plan.n_partitions,
+            max_blocks=plan.max_blocks, max_nj=plan.max_nj, hop=plan.hop,
+            twiddle=p(tw), audio=p(audio), ir=p(irs), wtab=p(wtab), events=p(events), streams=p(streams),
+            ir_energy=p(ir_energy), emitter_gain=p(gains), hspec=p(hspec), xspec=p(xspec), yspec=p(yspec),
+            spatial=p(spatial), partials=p(partials), event_stats=p(stats), event_scale=p(scale))
+        stream = mem.stream()
+        if stages is None:
+            lib.call("al_render_batch", ct.byref(b), stream)
+        else:
+            for name in stages:
+                lib.call(name, ct.byref(b), stream)
+        keep = (audio, events, streams, wtab, irs, ir_energy, hspec, xspec, yspec, partials, tw)
+        return RenderResult(plan=plan, memory=mem, lib=lib, spatial=spatial, event_scale=scale, event_stats=stats,
+                            emitter_gain=gains, keep=keep)
+
+    # -- A11
+    def mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()):
+        """scene (C, T) float32 on device.  ``ambience`` = [(device noise (C*T floats), device scalar)]."""
+        mem, lib = self.mem, self.lib
+        n = mix.n_capsules * mix.n_samples
+        stream = mem.stream()
+        scene = mem.zeros(n) if ambience else mem.empty(n)
+        for noise, a_dev in ambience:
+            lib.call("al_axpy", mem.ptr(scene), mem.ptr(noise), mem.ptr(a_dev), n, stream)
+        tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
+                                        mix.slot_count, mix.slot_rows, mix.slot_event)]
+        p = mem.ptr
+        m = _hip.AlMix(n_capsules=mix.n_capsules, n_samples=mix.n_samples, tile=mix.tile, n_tiles=mix.n_tiles,
+                       accumulate=1 if ambience else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
+                       slot_src=p(tabs[2]), slot_len=p(tabs[3]), slot_start=p(tabs[4]), slot_count=p(tabs[5]),
+                       slot_rows=p(tabs[6]), slot_event=p(tabs[7]), spatial=p(result.spatial),
+                       event_scale=p(result.event_scale), scene=p(scene))
+        lib.call("al_mixdown", ct.byref(m), stream)
+        self._mix_keep = tabs
+        return scene
+
+    def row_stats(self, x_dev, rows: int, cols: int):
+        n = self.lib.call("al_row_stats_partials", rows, cols)
+        partials = self.mem.empty(n)
+        out = self.mem.empty(rows * 4, np.float64)
+        self.lib.call("al_row_stats", self.mem.ptr(x_dev), rows, cols, self.mem.ptr(partials), self.mem.ptr(out),
+                      self.mem.stream())
+        return out

@@ -1,0 +1,152 @@
+/*
+ * audiblelight_hip.h -- C ABI of the MI355X (gfx950) spatial-audio synthesis path.
+ *
+ * Drop-in boundary for the hot path of AudibleLight's audiblelight/synthesize.py (reference paths
+ * below are relative to the AudibleLight repository).  The reference has no FFI of its own: its
+ * boundary is a set of Python functions that mutate Scene/Event objects.  The
+ * Python mirror of those functions lives in audiblelight_amd/synthesize.py and calls ONLY the entry
+ * points declared here (ctypes).  Every pointer marked "device" is a HIP device pointer to
+ * contiguous memory owned by the caller; the library never allocates, never frees, keeps no
+ * global state and never synchronises: every call only enqueues kernels on `stream`.
+ *
+ * Error convention: 0 = success, negative = AL_E_*; al_last_error() returns a thread-local string.
+ *
+ * Algorithm: uniformly partitioned overlap-save convolution with block size
+ * B = 2^log2_block.  Spectra of real 2B-sample windows are stored as B complex floats: bin 0
+ * packs (DC, Nyquist) in (re, im), bins 1..B-1 are ordinary.
+ */
+#ifndef AUDIBLELIGHT_HIP_H
+#define AUDIBLELIGHT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AL_OK 0
+#define AL_E_BADARG (-1)
+#define AL_E_HIP (-2)
+#define AL_E_UNSUPPORTED (-3)
+
+#define AL_MIN_LOG2_BLOCK 10
+#define AL_MAX_LOG2_BLOCK 14
+
+typedef void *al_stream_t; /* hipStream_t */
+
+/* One event as render_event_audio sees it (synthesize.py:507-608; attribute list SURVEY 8a A15). */
+typedef struct {
+  int64_t audio_off;  /* first sample of the mono clip inside `audio` */
+  int64_t out_off;    /* first element of this event's (C, len) block inside `spatial` */
+  int32_t len;        /* clip samples La = output samples per capsule (synthesize.py:553,590) */
+  int32_t valid_len;  /* convolution samples kept before zero padding: La for static events,
+                         min(La, n_frames*hop - win) for moving ones (synthesize.py:274,590) */
+  int32_t n_blocks;   /* K = ceil(len / B) output blocks */
+  int32_t stream0;    /* first entry of this event in the stream table */
+  int32_t n_streams;  /* emitters: 1 static, >1 moving (synthesize.py:564-587), 0 = tiled dry clip */
+  int32_t yspec_base; /* block index of (c=0,k=0) inside yspec; layout [c][k] */
+  int32_t part_base;  /* index of (c=0,k=0) inside the partial-statistics array; layout [c][k] */
+  float snr;          /* Event.snr */
+  float ref_db;       /* Scene.ref_db (synthesize.py:598) */
+  int32_t reserved;
+} al_event;
+
+/* One (event, emitter) source stream: the clip weighted by that emitter's cross-fade envelope
+ * (time_variant_convolution, synthesize.py:277-310, in the envelope form of SURVEY 8a A7). */
+typedef struct {
+  int32_t event;    /* owning event */
+  int32_t emitter;  /* column of the IR tensor (synthesize.py:662) */
+  int32_t j_lo;     /* first non-zero signal block */
+  int32_t n_j;      /* number of non-zero signal blocks */
+  int32_t xspec_base; /* block index of block j_lo inside xspec */
+  int32_t w_off;    /* offset of this stream's frame weights W[:, l] in `wtab`, -1 = static (env == 1) */
+  int32_t w_len;    /* number of frames n_frames = min(F_a, W.shape[0]) (synthesize.py:208-210) */
+  float gain;       /* clip gain folded into the spectrum (peak normalisation event.py:535-536,
+                       sample-wise FX gain/polarity, x fft_size for moving events) */
+} al_stream;
+
+/* Everything one launch sequence needs.  All pointers are device pointers unless noted. */
+typedef struct {
+  int32_t log2_block;   /* B = 1 << log2_block */
+  int32_t n_capsules;   /* C */
+  int32_t n_events;     /* E */
+  int32_t n_streams;    /* S */
+  int32_t n_emitters;   /* columns of the IR tensor used by this batch */
+  int32_t ir_len;       /* Lir samples per IR row */
+  int64_t ir_stride_c;  /* elements between capsules  (multiple of 4) */
+  int64_t ir_stride_n;  /* elements between emitters (multiple of 4) */
+  int32_t n_partitions; /* P = ceil(ir_len / B) */
+  int32_t max_blocks;   /* max over events of n_blocks */
+  int32_t max_nj;       /* max over streams of n_j */
+  int32_t hop;          /* STFT hop of the moving path (config.py:11), 128 */
+
+  const float *twiddle;   /* al_twiddle_init output, B complex */
+  const float *audio;     /* mono clips, float32 */
+  const float *ir;        /* IR tensor (C, N, Lir) float32: WorldState.get_irs() layout (worldstate.py:2183-2255) */
+  const float *wtab;      /* frame weights of moving streams */
+  const al_event *events;   /* E entries */
+  const al_stream *streams; /* S entries */
+
+  float *ir_energy;  /* workspace: n_emitters * C * P partial sums of ir^2 */
+  float *emitter_gain; /* workspace/out: n_emitters, 1 / mean_c ||ir||  (normalize_irs, synthesize.py:404-428) */
+  float *hspec;      /* workspace: n_emitters * C * P blocks of B complex */
+  float *xspec;      /* workspace: sum(n_j) blocks of B complex */
+  float *yspec;      /* workspace: sum(C * n_blocks) blocks of B complex */
+  float *spatial;    /* out: per event (C, len) float32, UNSCALED convolution truncated/padded to len */
+  float *partials;   /* workspace: 4 floats per (event, c, k): sum|x|, max|x|, non-finite count, pad */
+  double *event_stats; /* out: 4 doubles per event: sum|x|, max|x|, non-finite count, total scale */
+  float *event_scale;  /* out: per event multiplier = apply_snr o db_to_multiplier (synthesize.py:594-599) */
+} al_batch;
+
+/* Mixdown of one microphone (generate_scene_audio_from_events, synthesize.py:314-401). */
+typedef struct {
+  int32_t n_capsules;     /* rows of the scene buffer */
+  int32_t n_samples;      /* round(scene.duration * sample_rate) (synthesize.py:331) */
+  int32_t tile;           /* samples per time tile */
+  int32_t n_tiles;
+  int32_t accumulate;     /* 0: scene is overwritten, 1: scene already holds ambience (synthesize.py:335-356) */
+  int32_t reserved;
+  const int32_t *tile_ptr;  /* n_tiles + 1 */
+  const int32_t *tile_events; /* indices into the slot arrays, insertion order inside a tile */
+  const int64_t *slot_src;  /* per slot: offset of the event's (C, len) block inside `spatial` */
+  const int32_t *slot_len;  /* per slot: event len (row stride) */
+  const int32_t *slot_start; /* per slot: max(0, round(scene_start*sr)) (synthesize.py:361) */
+  const int32_t *slot_count; /* per slot: samples added = min(end-start, len) (synthesize.py:372-378) */
+  const int32_t *slot_rows;  /* per slot: capsules of that event */
+  const int32_t *slot_event; /* per slot: index into event_scale */
+  const float *spatial;
+  const float *event_scale;
+  float *scene;             /* (C, n_samples) float32 */
+} al_mix;
+
+const char *al_last_error(void);
+int al_abi_version(void);
+
+/* Bytes of the twiddle table for block 2^log2_block; al_twiddle_init fills it (device). */
+int64_t al_twiddle_bytes(int log2_block);
+int al_twiddle_init(float *twiddle, int log2_block, al_stream_t stream);
+
+/* Stage entry points (each only enqueues).  al_render_batch = stages 1-6 in order. */
+int al_ir_spectra(const al_batch *b, al_stream_t stream);      /* A1 energy partials + IR partition spectra */
+int al_emitter_gains(const al_batch *b, al_stream_t stream);   /* A1 normalize_irs scalar per emitter */
+int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 envelope + block spectra */
+int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
+int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
+int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */
+int al_render_batch(const al_batch *b, al_stream_t stream);
+
+/* A11 mixdown and helpers. */
+int al_mixdown(const al_mix *m, al_stream_t stream);
+/* x[r, :] *= scale[r_index] for a (rows, cols) block: scales an event's spatial audio in place
+ * (event.spatial_audio, synthesize.py:599,606). scale is a device pointer to ONE float. */
+int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream);
+/* y += a * x over n floats; a = *a_dev (ambience add, synthesize.py:350-356). */
+int al_axpy(float *y, const float *x, const float *a_dev, int64_t n, al_stream_t stream);
+/* Row statistics of a (rows, cols) float32 matrix: out[r] = {sum|x|, max|x|, non-finite count, 0} (doubles). */
+int al_row_stats(const float *x, int32_t rows, int64_t cols, float *partials, double *out, al_stream_t stream);
+int64_t al_row_stats_partials(int32_t rows, int64_t cols); /* floats needed in `partials` */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

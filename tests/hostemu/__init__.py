@@ -1,0 +1,52 @@
+"""TEST-ONLY host emulation of the HIP kernels (see hip/hip_runtime.h in this directory)."""
+import ctypes as ct
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+LIB = os.path.join(HERE, "_build", "libal_hostemu.so")
+SRC = os.path.join(ROOT, "audiblelight_amd", "csrc", "al_kernels.hip")
+
+
+def build(sanitize: bool = False) -> str:
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    deps = [SRC, os.path.join(ROOT, "audiblelight_amd", "csrc", "al_fft.h"),
+            os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
+    if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):
+        return LIB
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", HERE, SRC, "-o", LIB]
+    if sanitize:
+        cmd[3:3] = ["-fsanitize=address,undefined"]
+    subprocess.check_call(cmd)
+    return LIB
+
+
+class NumpyMemory:
+    """'Device memory' for the host-emulated kernels: plain numpy arrays."""
+
+    def stream(self):
+        return ct.c_void_p(0)
+
+    def empty(self, n, dtype=np.float32):
+        return np.full(max(int(n), 1), np.nan if np.dtype(dtype).kind == "f" else 0, dtype=dtype)
+
+    def zeros(self, n, dtype=np.float32):
+        return np.zeros(max(int(n), 1), dtype=dtype)
+
+    def upload(self, arr):
+        arr = np.ascontiguousarray(arr)
+        if arr.dtype.fields is not None:
+            arr = arr.view(np.uint8)
+        return arr.copy()
+
+    def ptr(self, buf):
+        return buf.ctypes.data
+
+    def download(self, buf):
+        return np.array(buf)
+
+    def synchronize(self):
+        pass

@@ -116,67 +116,53 @@ class Renderer:
             host[off: off + len(clip)] = clip
         return host
 
-    def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-               stages: Optional[Sequence[str]] = None) -> RenderResult:
-        """Run stages 1-6 for one batch.  ``irs`` is a (C, N, L) ndarray or a device buffer
-        returned by upload_irs (then ``ir_strides`` = (stride_c, stride_n))."""
-        mem, lib = self.mem, self.lib
+    def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None) -> "PreparedBatch":
+        """Upload inputs + tables and allocate every workspace/output buffer of one batch.
+        ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``)."""
+        mem = self.mem
         if isinstance(irs, np.ndarray):
             irs, ir_strides = self.upload_irs(irs)
-        audio = mem.upload(self.pack_audio(plan, clips))
-        events = mem.upload(plan.events)
-        streams = mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE))
-        wtab = mem.upload(plan.wtab)
         B = plan.block
-        ir_energy = mem.empty(plan.hspec_blocks)
-        gains = mem.empty(plan.n_emitters)
-        hspec = mem.empty(plan.hspec_blocks * B * 2)
-        xspec = mem.empty(plan.xspec_blocks * B * 2)
-        yspec = mem.empty(plan.yspec_blocks * B * 2)
-        spatial = mem.empty(plan.spatial_floats)
-        partials = mem.empty(plan.n_partials * 4)
-        stats = mem.empty(len(plan.events) * 4, np.float64)
-        scale = mem.empty(len(plan.events))
-        tw = self.twiddle(plan.log2_block)
-        p = mem.ptr
-        b = _hip.AlBatch(
+        bufs = dict(
+            audio=mem.upload(self.pack_audio(plan, clips)), ir=irs, events=mem.upload(plan.events),
+            streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
+            wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
+            ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
+            hspec=mem.empty(plan.hspec_blocks * B * 2), xspec=mem.empty(plan.xspec_blocks * B * 2),
+            yspec=mem.empty(plan.yspec_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
+            partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
+            event_scale=mem.empty(len(plan.events)))
+        desc = _hip.AlBatch(
             log2_block=plan.log2_block, n_capsules=plan.n_capsules, n_events=len(plan.events),
             n_streams=len(plan.streams), n_emitters=plan.n_emitters, ir_len=plan.ir_len,
             ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1], n_partitions=plan.n_partitions,
             max_blocks=plan.max_blocks, max_nj=plan.max_nj, hop=plan.hop,
-            twiddle=p(tw), audio=p(audio), ir=p(irs), wtab=p(wtab), events=p(events), streams=p(streams),
-            ir_energy=p(ir_energy), emitter_gain=p(gains), hspec=p(hspec), xspec=p(xspec), yspec=p(yspec),
-            spatial=p(spatial), partials=p(partials), event_stats=p(stats), event_scale=p(scale))
-        stream = mem.stream()
-        if stages is None:
-            lib.call("al_render_batch", ct.byref(b), stream)
-        else:
-            for name in stages:
-                lib.call(name, ct.byref(b), stream)
-        keep = (audio, events, streams, wtab, irs, ir_energy, hspec, xspec, yspec, partials, tw)
-        return RenderResult(plan=plan, memory=mem, lib=lib, spatial=spatial, event_scale=scale, event_stats=stats,
-                            emitter_gain=gains, keep=keep)
+            **{k: mem.ptr(v) for k, v in bufs.items()})
+        return PreparedBatch(self, plan, bufs, desc)
+
+    def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
+               stages: Optional[Sequence[str]] = None) -> RenderResult:
+        """prepare + run stages 1-6 for one batch."""
+        return self.prepare(plan, clips, irs, ir_strides).run(stages)
+
+    def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()) -> "PreparedMix":
+        mem = self.mem
+        n = mix.n_capsules * mix.n_samples
+        tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
+                                        mix.slot_count, mix.slot_rows, mix.slot_event)]
+        scene = mem.empty(n)
+        p = mem.ptr
+        desc = _hip.AlMix(n_capsules=mix.n_capsules, n_samples=mix.n_samples, tile=mix.tile, n_tiles=mix.n_tiles,
+                          accumulate=1 if ambience else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
+                          slot_src=p(tabs[2]), slot_len=p(tabs[3]), slot_start=p(tabs[4]), slot_count=p(tabs[5]),
+                          slot_rows=p(tabs[6]), slot_event=p(tabs[7]), spatial=p(result.spatial),
+                          event_scale=p(result.event_scale), scene=p(scene))
+        return PreparedMix(self, mix, desc, scene, list(ambience), tabs + [result])
 
     # -- A11
     def mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()):
         """scene (C, T) float32 on device.  ``ambience`` = [(device noise (C*T floats), device scalar)]."""
-        mem, lib = self.mem, self.lib
-        n = mix.n_capsules * mix.n_samples
-        stream = mem.stream()
-        scene = mem.zeros(n) if ambience else mem.empty(n)
-        for noise, a_dev in ambience:
-            lib.call("al_axpy", mem.ptr(scene), mem.ptr(noise), mem.ptr(a_dev), n, stream)
-        tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
-                                        mix.slot_count, mix.slot_rows, mix.slot_event)]
-        p = mem.ptr
-        m = _hip.AlMix(n_capsules=mix.n_capsules, n_samples=mix.n_samples, tile=mix.tile, n_tiles=mix.n_tiles,
-                       accumulate=1 if ambience else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
-                       slot_src=p(tabs[2]), slot_len=p(tabs[3]), slot_start=p(tabs[4]), slot_count=p(tabs[5]),
-                       slot_rows=p(tabs[6]), slot_event=p(tabs[7]), spatial=p(result.spatial),
-                       event_scale=p(result.event_scale), scene=p(scene))
-        lib.call("al_mixdown", ct.byref(m), stream)
-        self._mix_keep = tabs
-        return scene
+        return self.prepare_mixdown(mix, result, ambience).run()
 
     def row_stats(self, x_dev, rows: int, cols: int):
         n = self.lib.call("al_row_stats_partials", rows, cols)
@@ -185,3 +171,47 @@ class Renderer:
         self.lib.call("al_row_stats", self.mem.ptr(x_dev), rows, cols, self.mem.ptr(partials), self.mem.ptr(out),
                       self.mem.stream())
         return out
+
+
+class PreparedBatch:
+    """One batch with every buffer resident in HBM; ``run()`` only enqueues kernels."""
+
+    STAGES = ("al_ir_spectra", "al_emitter_gains", "al_signal_spectra", "al_spectral_mac", "al_block_synthesis",
+              "al_event_levels")
+
+    def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, desc: _hip.AlBatch):
+        self.renderer, self.plan, self.bufs, self.desc = renderer, plan, bufs, desc
+
+    def run(self, stages: Optional[Sequence[str]] = None) -> RenderResult:
+        lib, stream = self.renderer.lib, self.renderer.mem.stream()
+        if stages is None:
+            lib.call("al_render_batch", ct.byref(self.desc), stream)
+        else:
+            for name in stages:
+                lib.call(name, ct.byref(self.desc), stream)
+        return self.result()
+
+    def run_stage(self, name: str) -> None:
+        self.renderer.lib.call(name, ct.byref(self.desc), self.renderer.mem.stream())
+
+    def result(self) -> RenderResult:
+        b = self.bufs
+        return RenderResult(plan=self.plan, memory=self.renderer.mem, lib=self.renderer.lib, spatial=b["spatial"],
+                            event_scale=b["event_scale"], event_stats=b["event_stats"],
+                            emitter_gain=b["emitter_gain"], keep=(self,))
+
+
+class PreparedMix:
+    def __init__(self, renderer: Renderer, mix: MixPlan, desc: _hip.AlMix, scene, ambience, keep):
+        self.renderer, self.mix, self.desc, self.scene, self.ambience, self.keep = renderer, mix, desc, scene, ambience, keep
+
+    def run(self):
+        mem, lib = self.renderer.mem, self.renderer.lib
+        stream = mem.stream()
+        n = self.mix.n_capsules * self.mix.n_samples
+        if self.ambience:
+            self.scene.zero_() if hasattr(self.scene, "zero_") else self.scene.fill(0)
+            for noise, a_dev in self.ambience:
+                lib.call("al_axpy", mem.ptr(self.scene), mem.ptr(noise), mem.ptr(a_dev), n, stream)
+        lib.call("al_mixdown", ct.byref(self.desc), stream)
+        return self.scene

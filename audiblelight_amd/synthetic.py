@@ -1,0 +1,65 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md section 8d (host-side input generation only)."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from .plan import EventSpec
+
+CONFIGS = {
+    # name: sample_rate, capsules, events, emitters per event, ir_len, clip_len, scene seconds
+    "cfg1": dict(sr=24000, C=4, E=4, N=1, Lir=12000, La=48000, T=10.0),
+    "cfg2": dict(sr=48000, C=32, E=64, N=1, Lir=96000, La=192000, T=60.0),
+    "cfg3": dict(sr=48000, C=32, E=16, N=32, Lir=96000, La=372000, T=60.0),
+    "cfg4": dict(sr=48000, C=32, E=32, N=1, Lir=48000, La=192000, T=30.0),
+    "cfg5": dict(sr=48000, C=64, E=128, N=1, Lir=192000, La=192000, T=60.0),
+}
+
+
+@dataclass
+class SyntheticScene:
+    name: str
+    sr: int
+    duration: float
+    n_capsules: int
+    ir_len: int
+    clips: List[np.ndarray]     # float32, peak-normalised
+    irs: np.ndarray             # (C, sum N, Lir) float32
+    specs: List[EventSpec]
+    starts: List[float]
+
+    @property
+    def ends(self):
+        return [s + len(c) / self.sr for s, c in zip(self.starts, self.clips)]
+
+    def algorithmic_bytes(self) -> int:
+        """Inputs read once + scene.audio written once (SURVEY 8d "scene-only contract")."""
+        audio = sum(len(c) for c in self.clips) * 4
+        return audio + self.irs.size * 4 + self.n_capsules * round(self.duration * self.sr) * 4
+
+
+def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, **override) -> SyntheticScene:
+    """White-noise clips + exponentially decaying random IRs with a unit direct tap."""
+    cfg = dict(CONFIGS[name])
+    cfg.update(override)
+    sr, C, E, N = cfg["sr"], cfg["C"], cfg["E"], cfg["N"]
+    Lir, La, T = int(cfg["Lir"] * scale), int(cfg["La"] * scale), cfg["T"] * scale
+    rng = np.random.default_rng(1234 + scene_index)
+    decay = np.exp(-np.arange(Lir, dtype=np.float32) / np.float32(Lir / 6.9))
+    irs = np.empty((C, E * N, Lir), dtype=np.float32)
+    clips, specs, starts = [], [], []
+    for e in range(E):
+        a = rng.standard_normal(La, dtype=np.float32)
+        a = a / np.max(np.abs(a) + np.finfo(np.float32).tiny)
+        clips.append(a.astype(np.float32))
+        for n in range(N):
+            h = rng.standard_normal((C, Lir), dtype=np.float32) * decay
+            h[np.arange(C), rng.integers(48, min(960, Lir), size=C)] += 1.0
+            irs[:, e * N + n, :] = h
+        specs.append(EventSpec(n_samples=La, n_emitters=N, snr=float(rng.uniform(5, 30)), emitter0=e * N,
+                               is_moving=N > 1, duration=La / sr, ref_db=-65.0))
+        starts.append(float(rng.uniform(0, max(T - La / sr, 0.0))))
+    return SyntheticScene(name=name, sr=sr, duration=T, n_capsules=C, ir_len=Lir, clips=clips, irs=irs, specs=specs,
+                          starts=starts)

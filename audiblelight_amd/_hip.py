@@ -88,6 +88,10 @@ class Library:
                 f"`python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                 f"There is no CPU fallback.")
         self.path = path
+        # torch ships its own libamdhip64/libhsa-runtime64; load them first so this library binds to
+        # the SAME HIP runtime instance (two runtimes in one process cannot both own the GPU).
+        import torch  # noqa: F401
+
         self._dll = ct.CDLL(path)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(self._dll, name)  # AttributeError if the library does not export it

@@ -33,6 +33,8 @@ class AlBatch(ct.Structure):
         ("log2_block", ct.c_int32), ("n_capsules", ct.c_int32), ("n_events", ct.c_int32), ("n_streams", ct.c_int32),
         ("n_emitters", ct.c_int32), ("ir_len", ct.c_int32), ("ir_stride_c", ct.c_int64), ("ir_stride_n", ct.c_int64),
         ("n_partitions", ct.c_int32), ("max_blocks", ct.c_int32), ("max_nj", ct.c_int32), ("hop", ct.c_int32),
+        ("event0", ct.c_int32), ("stream0", ct.c_int32), ("emitter0", ct.c_int32), ("xspec_block0", ct.c_int32),
+        ("yspec_block0", ct.c_int32), ("reserved0", ct.c_int32),
         ("twiddle", ct.c_void_p), ("audio", ct.c_void_p), ("ir", ct.c_void_p), ("wtab", ct.c_void_p),
         ("events", ct.c_void_p), ("streams", ct.c_void_p),
         ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),

@@ -14,10 +14,23 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <type_traits>
+#include <utility>
+
 #include "../../include/audiblelight_hip.h"
 #include "al_fft.h"
 
 namespace al {
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // ------------------------------------------------------------------ block-wide reductions
 // sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
@@ -63,7 +76,7 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
   __shared__ float2 s[fft_lds_elems(LOG2M)];
   __shared__ float red[48];
   const int tid = threadIdx.x;
-  const int p = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const int p = blockIdx.x, c = blockIdx.y, n = b.emitter0 + blockIdx.z;
   const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
   const float *src = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)n * b.ir_stride_n + (int64_t)p * M;
   const int remaining = b.ir_len - p * M;  // samples of this partition that exist (may exceed M)
@@ -86,8 +99,9 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
   for (int m = 8; m < 16; ++m) v[m] = make_float2(0.f, 0.f);
 
   fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
-  const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;
-  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + blk * M);
+  const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;  // global (energy partials)
+  const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;  // chunk-local spectrum
+  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + hblk * M);
 
   float mx = 0.f, z = 0.f;
   block_reduce3(energy, mx, z, red, tid, T);
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
 // ------------------------------------------------------------------ 2. emitter gains (normalize_irs)
 // one wave per emitter: g = 1 / mean_c( sqrt(sum_t h^2) + tiny(float64) )   (synthesize.py:425-428)
 __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
-  const int n = blockIdx.x, lane = threadIdx.x;
+  const int n = b.emitter0 + blockIdx.x, lane = threadIdx.x;
   double acc = 0.0;
   for (int c = lane; c < b.n_capsules; c += 64) {
     const float *e = b.ir_energy + ((int64_t)n * b.n_capsules + c) * b.n_partitions;
@@ -127,7 +141,7 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch 
   constexpr int M = 1 << LOG2M, T = M / 16;
   __shared__ float2 s[fft_lds_elems(LOG2M)];
   const int tid = threadIdx.x;
-  const al_stream st = b.streams[blockIdx.y];
+  const al_stream st = b.streams[b.stream0 + blockIdx.y];
   if ((int)blockIdx.x >= st.n_j) return;
   const al_event ev = b.events[st.event];
   const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
@@ -145,23 +159,27 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch 
     v[m] = make_float2(x0, x1);
   }
   fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
-  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base + blockIdx.x) * M);
+  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M);
 }
 
 // ------------------------------------------------------------------ 4. frequency-domain accumulate
-// One thread per bin; KT output blocks accumulate in registers while the partitions stream by.
-template <int KT>
+// Y[k] = sum_p X[k-p] * H[p] is a Toeplitz product per frequency bin.  One thread owns one bin and
+// walks (k-tile x p-tile) pairs: the KT accumulators and PT partition spectra of the pair stay in
+// registers and the KT+PT-1 signal blocks on its anti-diagonals are loaded ONCE each, so a pair
+// costs KT+2*PT-1 loads for KT*PT complex FMAs (static register indices throughout).
+// Bin 0 packs (DC, Nyquist): two independent real products.
+template <int KT, int PT>
 __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   const int M = 1 << b.log2_block;
   const int f = blockIdx.x * 256 + threadIdx.x;
   const int c = blockIdx.y;
-  const al_event ev = b.events[blockIdx.z];
+  const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
   const int K = ev.n_blocks, P = b.n_partitions;
-  const bool packed = (f == 0);  // bin 0 holds (DC, Nyquist): two independent real products
+  const bool packed = (f == 0);
 
   for (int k0 = 0; k0 < K; k0 += KT) {
     float2 acc[KT];
@@ -169,34 +187,49 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
     for (int kk = 0; kk < KT; ++kk) acc[kk] = make_float2(0.f, 0.f);
     for (int l = 0; l < ev.n_streams; ++l) {
       const al_stream st = b.streams[ev.stream0 + l];
-      const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
+      const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;  // non-zero signal blocks [jlo, jhi)
+      if (jhi <= jlo) continue;
+      // partitions that can meet this k-tile: k0+kk-p in [jlo, jhi)
       const int plo = max(0, k0 - jhi + 1), phi = min(P - 1, k0 + KT - 1 - jlo);
       if (plo > phi) continue;
       const float g = b.emitter_gain[st.emitter];
-      const float2 *hp = H + (((int64_t)st.emitter * b.n_capsules + c) * P) * M + f;
-      const float2 *xp = X + (int64_t)(st.xspec_base - jlo) * M + f;
-      for (int p = plo; p <= phi; ++p) {
-        float2 h = hp[(int64_t)p * M];
-        h.x *= g;
-        h.y *= g;
+      const float2 *hp = H + (((int64_t)(st.emitter - b.emitter0) * b.n_capsules + c) * P) * M + f;
+      const float2 *xp = X + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
+      for (int p0 = plo; p0 <= phi; p0 += PT) {
+        float2 h[PT];
 #pragma unroll
-        for (int kk = 0; kk < KT; ++kk) {
-          const int j = k0 + kk - p;
-          if (j >= jlo && j < jhi) {
-            const float2 x = xp[(int64_t)j * M];
-            if (packed) {
-              acc[kk].x = fmaf(x.x, h.x, acc[kk].x);
-              acc[kk].y = fmaf(x.y, h.y, acc[kk].y);
-            } else {
-              cfma(acc[kk], x, h);
-            }
+        for (int pp = 0; pp < PT; ++pp) {
+          h[pp] = make_float2(0.f, 0.f);
+          if (p0 + pp <= phi) {
+            const float2 v = hp[(int64_t)(p0 + pp) * M];
+            h[pp] = make_float2(v.x * g, v.y * g);
           }
         }
+        const int jbase = k0 - p0 - (PT - 1);  // signal block of anti-diagonal jj is jbase + jj
+        static_for<KT + PT - 1>([&](auto jj_c) {
+          constexpr int jj = decltype(jj_c)::value;
+          const int j = jbase + jj;
+          if (j >= jlo && j < jhi) {
+            const float2 x = xp[(int64_t)j * M];
+            static_for<KT>([&](auto kk_c) {
+              constexpr int kk = decltype(kk_c)::value;
+              constexpr int pp = kk + (PT - 1) - jj;
+              if constexpr (pp >= 0 && pp < PT) {
+                if (packed) {
+                  acc[kk].x = fmaf(x.x, h[pp].x, acc[kk].x);
+                  acc[kk].y = fmaf(x.y, h[pp].y, acc[kk].y);
+                } else {
+                  cfma(acc[kk], x, h[pp]);
+                }
+              }
+            });
+          }
+        });
       }
     }
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
-      if (k0 + kk < K) Y[((int64_t)ev.yspec_base + (int64_t)c * K + k0 + kk) * M + f] = acc[kk];
+      if (k0 + kk < K) Y[((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f] = acc[kk];
   }
 }
 
@@ -208,7 +241,7 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch
   __shared__ float red[48];
   const int tid = threadIdx.x;
   const int k = blockIdx.x, c = blockIdx.y;
-  const al_event ev = b.events[blockIdx.z];
+  const al_event ev = b.events[b.event0 + blockIdx.z];
   if (k >= ev.n_blocks) return;
   const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
   float *out = b.spatial + ev.out_off + (int64_t)c * ev.len;
@@ -230,7 +263,7 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch
       }
     }
   } else {
-    const float2 *y = reinterpret_cast<const float2 *>(b.yspec) + ((int64_t)ev.yspec_base + (int64_t)c * ev.n_blocks + k) * M;
+    const float2 *y = reinterpret_cast<const float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks + k) * M;
     real_pack_load<LOG2M>(y, s, tw, tid, 1.0f / (float)M);
     __syncthreads();
     float2 v[16];
@@ -283,7 +316,8 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch
 // Composite of apply_snr (synthesize.py:40-49) and db_to_multiplier (synthesize.py:52-68) as chained
 // at synthesize.py:594-599, evaluated in float64 from the deterministic partial statistics.
 __global__ __launch_bounds__(64) void k_event_levels(al_batch b) {
-  const al_event ev = b.events[blockIdx.x];
+  const int e = b.event0 + blockIdx.x;
+  const al_event ev = b.events[e];
   const int lane = threadIdx.x;
   const int n = b.n_capsules * ev.n_blocks;
   const float *pp = b.partials + 4 * (int64_t)ev.part_base;
@@ -306,12 +340,12 @@ __global__ __launch_bounds__(64) void k_event_levels(al_batch b) {
     const double s1 = snr / peak;                                   // apply_snr
     const double mean_abs = fabs(s1) * sum / ((double)b.n_capsules * (double)ev.len);
     const double s2 = pow(10.0, ((double)ev.ref_db + snr) / 20.0) / (mean_abs + 2.2250738585072014e-308);
-    double *o = b.event_stats + 4 * (int64_t)blockIdx.x;
+    double *o = b.event_stats + 4 * (int64_t)e;
     o[0] = sum;
     o[1] = (double)mx;
     o[2] = bad;
     o[3] = s2;
-    b.event_scale[blockIdx.x] = (float)(s1 * s2);
+    b.event_scale[e] = (float)(s1 * s2);
   }
 }
 
@@ -487,7 +521,16 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->n_emitters <= 0) return AL_OK;
   const dim3 grid((1 << b->log2_block) / 256, b->n_capsules, b->n_events);
-  hipLaunchKernelGGL((al::k_spectral_mac<8>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers
+  const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
+  if (wide_k && wide_p)
+    hipLaunchKernelGGL((al::k_spectral_mac<24, 12>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  else if (wide_k)
+    hipLaunchKernelGGL((al::k_spectral_mac<24, 4>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  else if (wide_p)
+    hipLaunchKernelGGL((al::k_spectral_mac<8, 12>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  else
+    hipLaunchKernelGGL((al::k_spectral_mac<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, *b);
   return check_launch("k_spectral_mac");
 }
 

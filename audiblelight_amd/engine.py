@@ -116,34 +116,42 @@ class Renderer:
             host[off: off + len(clip)] = clip
         return host
 
-    def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None) -> "PreparedBatch":
+    def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
+                chunk_events: Optional[int] = None) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
-        ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``)."""
+        ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
+        ``chunk_events``: run the batch as chunks of that many events over one reused spectra workspace."""
         mem = self.mem
         if isinstance(irs, np.ndarray):
             irs, ir_strides = self.upload_irs(irs)
         B = plan.block
+        chunks = plan.chunks(chunk_events)
+        P, C = plan.n_partitions, plan.n_capsules
+        h_blocks = max(max(c["n_emitters"] for c in chunks) * C * P, 1)
+        x_blocks = max(max(c["xspec_blocks"] for c in chunks), 1)
+        y_blocks = max(max(c["yspec_blocks"] for c in chunks), 1)
         bufs = dict(
             audio=mem.upload(self.pack_audio(plan, clips)), ir=irs, events=mem.upload(plan.events),
             streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
             wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
-            hspec=mem.empty(plan.hspec_blocks * B * 2), xspec=mem.empty(plan.xspec_blocks * B * 2),
-            yspec=mem.empty(plan.yspec_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
+            hspec=mem.empty(h_blocks * B * 2), xspec=mem.empty(x_blocks * B * 2),
+            yspec=mem.empty(y_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
             partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
             event_scale=mem.empty(len(plan.events)))
-        desc = _hip.AlBatch(
-            log2_block=plan.log2_block, n_capsules=plan.n_capsules, n_events=len(plan.events),
-            n_streams=len(plan.streams), n_emitters=plan.n_emitters, ir_len=plan.ir_len,
-            ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1], n_partitions=plan.n_partitions,
-            max_blocks=plan.max_blocks, max_nj=plan.max_nj, hop=plan.hop,
-            **{k: mem.ptr(v) for k, v in bufs.items()})
-        return PreparedBatch(self, plan, bufs, desc)
+        ptrs = {k: mem.ptr(v) for k, v in bufs.items()}
+        descs = [_hip.AlBatch(
+            log2_block=plan.log2_block, n_capsules=C, n_events=c["n_events"], n_streams=c["n_streams"],
+            n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
+            n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
+            stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
+            yspec_block0=c["yspec_block0"], **ptrs) for c in chunks]
+        return PreparedBatch(self, plan, bufs, descs)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-               stages: Optional[Sequence[str]] = None) -> RenderResult:
+               stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None) -> RenderResult:
         """prepare + run stages 1-6 for one batch."""
-        return self.prepare(plan, clips, irs, ir_strides).run(stages)
+        return self.prepare(plan, clips, irs, ir_strides, chunk_events).run(stages)
 
     def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()) -> "PreparedMix":
         mem = self.mem
@@ -179,20 +187,21 @@ class PreparedBatch:
     STAGES = ("al_ir_spectra", "al_emitter_gains", "al_signal_spectra", "al_spectral_mac", "al_block_synthesis",
               "al_event_levels")
 
-    def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, desc: _hip.AlBatch):
-        self.renderer, self.plan, self.bufs, self.desc = renderer, plan, bufs, desc
+    def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, descs: List[_hip.AlBatch]):
+        self.renderer, self.plan, self.bufs, self.descs = renderer, plan, bufs, descs
 
     def run(self, stages: Optional[Sequence[str]] = None) -> RenderResult:
         lib, stream = self.renderer.lib, self.renderer.mem.stream()
-        if stages is None:
-            lib.call("al_render_batch", ct.byref(self.desc), stream)
-        else:
-            for name in stages:
-                lib.call(name, ct.byref(self.desc), stream)
+        for desc in self.descs:
+            if stages is None:
+                lib.call("al_render_batch", ct.byref(desc), stream)
+            else:
+                for name in stages:
+                    lib.call(name, ct.byref(desc), stream)
         return self.result()
 
-    def run_stage(self, name: str) -> None:
-        self.renderer.lib.call(name, ct.byref(self.desc), self.renderer.mem.stream())
+    def run_stage(self, name: str, chunk: int = 0) -> None:
+        self.renderer.lib.call(name, ct.byref(self.descs[chunk]), self.renderer.mem.stream())
 
     def result(self) -> RenderResult:
         b = self.bufs

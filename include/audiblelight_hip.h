@@ -71,7 +71,7 @@ typedef struct {
   int32_t n_capsules;   /* C */
   int32_t n_events;     /* E */
   int32_t n_streams;    /* S */
-  int32_t n_emitters;   /* columns of the IR tensor used by this batch */
+  int32_t n_emitters;   /* columns of the IR tensor used by this batch: [emitter0, emitter0 + n_emitters) */
   int32_t ir_len;       /* Lir samples per IR row */
   int64_t ir_stride_c;  /* elements between capsules  (multiple of 4) */
   int64_t ir_stride_n;  /* elements between emitters (multiple of 4) */
@@ -79,6 +79,18 @@ typedef struct {
   int32_t max_blocks;   /* max over events of n_blocks */
   int32_t max_nj;       /* max over streams of n_j */
   int32_t hop;          /* STFT hop of the moving path (config.py:11), 128 */
+  /* Chunking.  A long scene is run as several batches ("chunks") over ONE set of global tables: a chunk
+   * covers events [event0, event0+n_events), streams [stream0, stream0+n_streams) and IR columns
+   * [emitter0, emitter0+n_emitters).  hspec/xspec/yspec are chunk-local workspaces that every chunk reuses
+   * (so they stay in the 256 MiB Infinity Cache instead of round-tripping through HBM): global block
+   * indices from the tables are rebased by xspec_block0 / yspec_block0 / emitter0.  ir_energy,
+   * emitter_gain, partials, spatial, event_stats and event_scale are indexed globally. */
+  int32_t event0;
+  int32_t stream0;
+  int32_t emitter0;
+  int32_t xspec_block0;
+  int32_t yspec_block0;
+  int32_t reserved0;
 
   const float *twiddle;   /* al_twiddle_init output, B complex */
   const float *audio;     /* mono clips, float32 */
@@ -89,7 +101,7 @@ typedef struct {
 
   float *ir_energy;  /* workspace: n_emitters * C * P partial sums of ir^2 */
   float *emitter_gain; /* workspace/out: n_emitters, 1 / mean_c ||ir||  (normalize_irs, synthesize.py:404-428) */
-  float *hspec;      /* workspace: n_emitters * C * P blocks of B complex */
+  float *hspec;      /* workspace: n_emitters * C * P blocks of B complex, [n - emitter0][c][p] */
   float *xspec;      /* workspace: sum(n_j) blocks of B complex */
   float *yspec;      /* workspace: sum(C * n_blocks) blocks of B complex */
   float *spatial;    /* out: per event (C, len) float32, UNSCALED convolution truncated/padded to len */

@@ -86,6 +86,12 @@ def test_emu_full_scene_with_ambience(emu, golden):
     res = emu.render(pl, clips, mic_ir)
     for i in range(len(specs)):
         assert rel_rms(res.spatial_audio(i), golden[f"g8_spatial{i}"]) < TOL
+    # chunked execution over a reused workspace gives bit-identical results
+    for chunk in (1, 2):
+        res_c = emu.render(pl, clips, mic_ir, chunk_events=chunk)
+        np.testing.assert_array_equal(res_c.scales(), res.scales())
+        for i in range(len(specs)):
+            np.testing.assert_array_equal(res_c.raw_spatial(i), res.raw_spatial(i))
     starts = [float(s[2]) for s in golden["g8_specs"]]
     ends = [s + len(c) / sr for s, c in zip(starts, clips)]
     mix = planning.plan_mixdown(starts, ends, [len(c) for c in clips], [C] * 5, pl.events["out_off"],

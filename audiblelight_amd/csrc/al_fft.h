@@ -129,6 +129,33 @@ __device__ __forceinline__ void twiddle_powers(float2 (&w)[16], float2 a, float2
   }
 }
 
+// Twiddle base factors of one pass (one (w^1, w^4) pair per butterfly), loaded a pass ahead so
+// the L2 round trip overlaps the previous pass's butterflies and barriers.
+template <int LOG2M, int PASS>
+struct PassTwiddles {
+  static constexpr int NB = 16 / fft_radix(LOG2M, PASS);
+  float2 a[NB], c[NB];
+};
+
+template <int LOG2M, int DIR, int PASS>
+__device__ __forceinline__ void load_pass_twiddles(PassTwiddles<LOG2M, PASS> &t, const float2 *__restrict__ tw, int tid) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  constexpr int R = fft_radix(LOG2M, PASS);
+  constexpr int NS = 1 << (4 * PASS);
+  constexpr int NB = 16 / R;
+  constexpr int STEP = 2 * M / (NS * R);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const int k = (tid + T * b) & (NS - 1);
+    t.a[b] = tw[k * STEP];
+    t.c[b] = (R > 4) ? tw[4 * k * STEP] : t.a[b];
+    if (DIR > 0) {
+      t.a[b].y = -t.a[b].y;
+      t.c[b].y = -t.c[b].y;
+    }
+  }
+}
+
 // One Stockham pass.  On entry (PASS == 0) v[m] holds in[tid + T*m]; later passes read those
 // slots from LDS themselves.  Outputs are scattered to LDS; the caller must have a barrier
 // between the last read of the LDS image and this call's writes when PASS == 0.
@@ -136,7 +163,7 @@ __device__ __forceinline__ void twiddle_powers(float2 (&w)[16], float2 a, float2
 //   k = j mod NS;  factor exp(DIR*2*pi*i*r*k/(NS*R))
 //   out[(j - k)*R + k + q*NS] = X[q]
 template <int LOG2M, int DIR, int PASS>
-__device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
+__device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassTwiddles<LOG2M, PASS> &t, int tid) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   constexpr int R = fft_radix(LOG2M, PASS);
   constexpr int NS = 1 << (4 * PASS);
@@ -144,27 +171,16 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const float
   if (PASS > 0) {
 #pragma unroll
     for (int m = 0; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
-  }
 #pragma unroll
-  for (int b = 0; b < NB; ++b) {
-    const int j = tid + T * b;
-    const int k = j & (NS - 1);
-    if (PASS > 0) {
-      constexpr int STEP = 2 * M / (NS * R);
-      float2 a = tw[k * STEP];
-      float2 c = (R > 4) ? tw[4 * k * STEP] : a;
-      if (DIR > 0) {
-        a.y = -a.y;
-        c.y = -c.y;
-      }
+    for (int b = 0; b < NB; ++b) {
       float2 w[16];
-      twiddle_powers<R>(w, a, c);
+      twiddle_powers<R>(w, t.a[b], t.c[b]);
 #pragma unroll
       for (int r = 1; r < R; ++r) v[b + r * NB] = cmul(v[b + r * NB], w[r]);
     }
+    // all LDS reads of this pass are done once every thread is here
+    __syncthreads();
   }
-  // all LDS reads of this pass are done once every thread is here
-  if (PASS > 0) __syncthreads();
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int j = tid + T * b;
@@ -200,9 +216,16 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const float
 
 template <int LOG2M, int DIR, int PASS>
 struct FftPasses {
-  static __device__ __forceinline__ void run(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
-    fft_pass<LOG2M, DIR, PASS>(v, s, tw, tid);
-    if constexpr (PASS + 1 < fft_npasses(LOG2M)) FftPasses<LOG2M, DIR, PASS + 1>::run(v, s, tw, tid);
+  static __device__ __forceinline__ void run(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid,
+                                             const PassTwiddles<LOG2M, PASS> &cur) {
+    if constexpr (PASS + 1 < fft_npasses(LOG2M)) {
+      PassTwiddles<LOG2M, PASS + 1> nxt;
+      load_pass_twiddles<LOG2M, DIR, PASS + 1>(nxt, tw, tid);  // in flight during this pass
+      fft_pass<LOG2M, DIR, PASS>(v, s, cur, tid);
+      FftPasses<LOG2M, DIR, PASS + 1>::run(v, s, tw, tid, nxt);
+    } else {
+      fft_pass<LOG2M, DIR, PASS>(v, s, cur, tid);
+    }
   }
 };
 
@@ -210,7 +233,8 @@ struct FftPasses {
 // in the padded LDS image s[lds_pad(k)], visible to every thread (ends with a barrier).
 template <int LOG2M, int DIR>
 __device__ __forceinline__ void fft_regs_to_lds(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
-  FftPasses<LOG2M, DIR, 0>::run(v, s, tw, tid);
+  PassTwiddles<LOG2M, 0> none;  // pass 0 has unit twiddles
+  FftPasses<LOG2M, DIR, 0>::run(v, s, tw, tid, none);
 }
 
 // ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)

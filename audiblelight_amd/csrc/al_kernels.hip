@@ -82,18 +82,24 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
   const int remaining = b.ir_len - p * M;  // samples of this partition that exist (may exceed M)
   float2 v[16];
   float energy = 0.f;
+  // first half of the 2B window = the partition, second half zero.  Loads are unconditional
+  // (clamped addresses + selects) so all eight are in flight together.
+  if (remaining >= M) {  // workgroup-uniform
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {  // first half of the 2B window = the partition, second half zero
-    const int t = 2 * (tid + T * m);
-    float2 x = make_float2(0.f, 0.f);
-    if (t + 1 < remaining) {
-      x = *reinterpret_cast<const float2 *>(src + t);  // rows are 16-byte aligned, t is even
-    } else if (t < remaining) {
-      x.x = src[t];
+    for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float2 *>(src + 2 * (tid + T * m));
+  } else {
+    const int last = remaining - 1;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int t = 2 * (tid + T * m);
+      const float x0 = src[min(t, last)], x1 = src[min(t + 1, last)];
+      v[m] = make_float2(t <= last ? x0 : 0.f, t + 1 <= last ? x1 : 0.f);
     }
-    v[m] = x;
-    energy = fmaf(x.x, x.x, energy);
-    energy = fmaf(x.y, x.y, energy);
+  }
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    energy = fmaf(v[m].x, v[m].x, energy);
+    energy = fmaf(v[m].y, v[m].y, energy);
   }
 #pragma unroll
   for (int m = 8; m < 16; ++m) v[m] = make_float2(0.f, 0.f);
@@ -131,8 +137,9 @@ __device__ __forceinline__ float stream_envelope(const float *__restrict__ w, in
   const int q = t / hop, r = t - q * hop;
   const float sn = sinpif((float)r / (float)(2 * hop));
   const float win = sn * sn;
-  const float w0 = q < w_len ? w[q] : 0.f;
-  const float w1 = q + 1 < w_len ? w[q + 1] : 0.f;
+  const float a0 = w[min(q, w_len - 1)], a1 = w[min(q + 1, w_len - 1)];  // unconditional loads
+  const float w0 = q < w_len ? a0 : 0.f;
+  const float w1 = q + 1 < w_len ? a1 : 0.f;
   return fmaf(w1 - w0, win, w0);
 }
 
@@ -146,17 +153,33 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch 
   const al_event ev = b.events[st.event];
   const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
   const float *a = b.audio + ev.audio_off;
-  const float *w = st.w_off >= 0 ? b.wtab + st.w_off : nullptr;
+  const bool moving = st.w_off >= 0 && st.w_len > 0;
+  const float *w = b.wtab + (moving ? st.w_off : 0);
   const int j = st.j_lo + blockIdx.x;
   const int t0 = (j - 1) * M;  // window [(j-1)B, (j+1)B)
+  const int last = ev.len - 1;
   float2 v[16];
+  if (t0 >= 0 && t0 + 2 * M <= ev.len) {  // interior window (workgroup-uniform): aligned pair loads
+#pragma unroll
+    for (int m = 0; m < 16; ++m) v[m] = *reinterpret_cast<const float2 *>(a + t0 + 2 * (tid + T * m));
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int t = t0 + 2 * (tid + T * m);
+      const float x0 = a[min(max(t, 0), last)], x1 = a[min(max(t + 1, 0), last)];
+      v[m] = make_float2((t >= 0 && t <= last) ? x0 : 0.f, (t + 1 >= 0 && t + 1 <= last) ? x1 : 0.f);
+    }
+  }
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     const int t = t0 + 2 * (tid + T * m);
-    float x0 = 0.f, x1 = 0.f;
-    if (t >= 0 && t < ev.len) x0 = a[t] * st.gain * (w ? stream_envelope(w, st.w_len, b.hop, t) : 1.f);
-    if (t + 1 >= 0 && t + 1 < ev.len) x1 = a[t + 1] * st.gain * (w ? stream_envelope(w, st.w_len, b.hop, t + 1) : 1.f);
-    v[m] = make_float2(x0, x1);
+    float g0 = st.gain, g1 = st.gain;
+    if (moving) {  // workgroup-uniform
+      g0 *= stream_envelope(w, st.w_len, b.hop, max(t, 0));
+      g1 *= stream_envelope(w, st.w_len, b.hop, max(t + 1, 0));
+    }
+    v[m].x *= g0;
+    v[m].y *= g1;
   }
   fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
   real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M);
@@ -199,18 +222,20 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
         float2 h[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) {
-          h[pp] = make_float2(0.f, 0.f);
-          if (p0 + pp <= phi) {
-            const float2 v = hp[(int64_t)(p0 + pp) * M];
-            h[pp] = make_float2(v.x * g, v.y * g);
-          }
+          // unconditional load at a clamped partition, zeroed by the select: keeps all PT loads in flight
+          const float2 v = hp[(int64_t)min(p0 + pp, phi) * M];
+          const float gm = (p0 + pp <= phi) ? g : 0.f;
+          h[pp] = make_float2(v.x * gm, v.y * gm);
         }
         const int jbase = k0 - p0 - (PT - 1);  // signal block of anti-diagonal jj is jbase + jj
         static_for<KT + PT - 1>([&](auto jj_c) {
           constexpr int jj = decltype(jj_c)::value;
           const int j = jbase + jj;
-          if (j >= jlo && j < jhi) {
-            const float2 x = xp[(int64_t)j * M];
+          {
+            float2 x = xp[(int64_t)min(max(j, jlo), jhi - 1) * M];  // clamped, unconditional
+            const bool live = (j >= jlo && j < jhi);
+            x.x = live ? x.x : 0.f;
+            x.y = live ? x.y : 0.f;
             static_for<KT>([&](auto kk_c) {
               constexpr int kk = decltype(kk_c)::value;
               constexpr int pp = kk + (PT - 1) - jj;

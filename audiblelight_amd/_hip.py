@@ -16,6 +16,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
+FLAG_NO_IR_NORM = 1
 
 # numpy mirrors of al_event / al_stream (the tables are built on the host and copied to HBM)
 EVENT_DTYPE = np.dtype([
@@ -34,7 +35,7 @@ class AlBatch(ct.Structure):
         ("n_emitters", ct.c_int32), ("ir_len", ct.c_int32), ("ir_stride_c", ct.c_int64), ("ir_stride_n", ct.c_int64),
         ("n_partitions", ct.c_int32), ("max_blocks", ct.c_int32), ("max_nj", ct.c_int32), ("hop", ct.c_int32),
         ("event0", ct.c_int32), ("stream0", ct.c_int32), ("emitter0", ct.c_int32), ("xspec_block0", ct.c_int32),
-        ("yspec_block0", ct.c_int32), ("reserved0", ct.c_int32),
+        ("yspec_block0", ct.c_int32), ("flags", ct.c_int32),
         ("twiddle", ct.c_void_p), ("audio", ct.c_void_p), ("ir", ct.c_void_p), ("wtab", ct.c_void_p),
         ("events", ct.c_void_p), ("streams", ct.c_void_p),
         ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),
@@ -76,7 +77,15 @@ SYMBOLS = {
     "al_axpy": (ct.c_int, [_P, _P, _P, ct.c_int64, _S]),
     "al_row_stats": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _P, _S]),
     "al_row_stats_partials": (ct.c_int64, [ct.c_int32, ct.c_int64]),
+    "al_fx_apply": (ct.c_int, [ct.c_int, _P, _P, ct.c_int64, _P, _P, _S]),
+    "al_fx_frame_shuffle": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _P, ct.c_int32, _S]),
+    "al_wrap_copy": (ct.c_int, [_P, ct.c_int64, _P, ct.c_int64, _S]),
+    "al_noise_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int64]),
+    "al_noise_irfft": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
+    "al_scale_matrix_rows": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _S]),
 }
+FX_GAIN, FX_INVERT, FX_REVERSE, FX_FADE, FX_CLIP, FX_TANH, FX_BITCRUSH, FX_PREEMPH, FX_DEEMPH = range(1, 10)
+FADE_SHAPES = {"linear": 0, "exponential": 1, "logarithmic": 2, "quarter_sine": 3, "half_sine": 4, "none": 5}
 
 
 class Library:

@@ -1,0 +1,208 @@
+"""Background ambience on the GPU with the reference's ``Ambience`` / ``powerlaw_psd_gaussian`` API
+(audiblelight/ambience.py).
+
+Random draws come from numpy on the host, exactly where the reference takes them (default_rng(seed)
+for coloured noise, the global RNG for "gaussian"): its PCG64 + ziggurat stream is data-dependent and is
+deliberately not re-implemented on the device, so for a fixed seed the noise equals the reference's up to
+float32 rounding.  Everything after the draws runs in HIP kernels: spectral shaping, the DC / Nyquist
+fix-ups, an arbitrary-length inverse real FFT, the 1/sigma scale, per-channel peak normalisation and
+the tiling of file-based ambience.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Any, Iterable, Optional, Union
+
+import numpy as np
+
+from . import config
+from .utils import tiny, valid_audio
+
+# popular names -> beta (higher beta = more low-frequency energy), reference ambience.py:23
+NOISE_MAPPING = dict(pink=1, brown=2, red=2, blue=-1, white=0, violet=-2)
+
+
+def _renderer():
+    from . import synthesize
+
+    return synthesize.get_renderer()
+
+
+def _parse_beta(noise: Any) -> Union[float, str]:
+    """Colour name / "gaussian" / numeric exponent -> beta (reference ambience.py:378-400)."""
+    if isinstance(noise, str):
+        if noise in NOISE_MAPPING:
+            return NOISE_MAPPING[noise]
+        if noise.lower() == "gaussian":
+            return "gaussian"
+        raise KeyError(f"Expected a string in {', '.join(NOISE_MAPPING)} but got {noise}.")
+    if isinstance(noise, (int, float, np.integer, np.floating)) and not isinstance(noise, bool):
+        return noise
+    raise TypeError(f"Expected either a string or numeric input, but got {type(noise)}.")
+
+
+def _spectral_shape(beta: float, samples: int, fmin: float):
+    """Scaling vector s[f] and theoretical output std sigma (reference ambience.py:319-340). Host side:
+    one pass over samples/2+1 frequencies, no audio involved."""
+    if not isinstance(fmin, (int, float, np.integer, np.floating)) or fmin < 0:
+        raise ValueError(f"Expected a positive numeric input, but got {fmin}")
+    if not 0 <= fmin <= 0.5:
+        raise ValueError(f"Argument `fmin` must be chosen between 0 and 0.5 but got {fmin:.2f}.")
+    f = np.fft.rfftfreq(samples)
+    fmin = max(fmin, 1.0 / (samples + tiny(samples)))
+    cut = int(np.sum(f < fmin))
+    if cut and cut < len(f):
+        f[:cut] = f[cut]
+    s = f ** (-beta / 2.0)
+    w = s[1:].copy()
+    w[-1] *= (1 + (samples % 2)) / 2.0
+    sigma = 2 * np.sqrt(np.sum(w ** 2)) / (samples + tiny(samples))
+    return s, sigma
+
+
+def powerlaw_noise_device(renderer, beta: float, rows: int, samples: int, fmin: float = 0.0,
+                          seed: Optional[int] = config.SEED):
+    """Device buffer (rows*samples float32) of Gaussian (1/f)^beta noise."""
+    s, sigma = _spectral_shape(beta, samples, fmin)
+    rng = np.random.default_rng(seed)
+    bins = samples // 2 + 1
+    zr = rng.normal(size=(rows, bins)).astype(np.float32)   # same draw order as ambience.py:355-356
+    zi = rng.normal(size=(rows, bins)).astype(np.float32)
+    r = renderer
+    d_zr, d_zi, d_s = r.mem.upload(zr.reshape(-1)), r.mem.upload(zi.reshape(-1)), r.mem.upload(s.astype(np.float32))
+    work = r.mem.empty(r.lib.call("al_noise_workspace_floats", rows, samples))
+    out = r.mem.empty(rows * samples)
+    r.lib.call("al_noise_irfft", r.mem.ptr(d_zr), r.mem.ptr(d_zi), r.mem.ptr(d_s), rows, samples,
+               float(1.0 / sigma), r.mem.ptr(out), r.mem.ptr(work), r.mem.stream())
+    r.mem.synchronize()
+    return out
+
+
+def powerlaw_psd_gaussian(beta, shape: Union[int, Iterable[int]], fmin: Optional[float] = 0.0,
+                          seed: Optional[int] = config.SEED) -> np.ndarray:
+    """Gaussian (1/f)**beta noise, last axis = time (reference ambience.py:271-375; Timmer & Koenig 1995)."""
+    if isinstance(shape, (np.integer, int)):
+        size = [int(shape)]
+    elif isinstance(shape, Iterable):
+        size = [int(v) for v in shape]
+    else:
+        raise ValueError(f"Argument `shape` must be of type int or Iterable[int] but got {type(shape)}")
+    samples = size[-1]
+    rows = int(np.prod(size[:-1])) if len(size) > 1 else 1
+    r = _renderer()
+    dev = powerlaw_noise_device(r, beta, rows, samples, fmin, seed)
+    return r.mem.download(dev)[: rows * samples].reshape(size).astype(np.float64)
+
+
+def peak_normalize_rows_device(renderer, dev, rows: int, cols: int) -> None:
+    """Per-channel ``ch / max(|ch| + tiny)`` in place (reference ambience.py:211-214)."""
+    r = renderer
+    stats = r.mem.download(r.row_stats(dev, rows, cols)).reshape(-1, 4)[:rows]
+    scale = (1.0 / (stats[:, 1] + tiny(np.float64(0)))).astype(np.float32)
+    r.lib.call("al_scale_matrix_rows", r.mem.ptr(dev), rows, cols, r.mem.ptr(r.mem.upload(scale)), r.mem.stream())
+    r.mem.synchronize()
+
+
+class Ambience:
+    """Persistent background noise of a Scene (reference ambience.py:26-267): coloured noise or a tiled clip."""
+
+    def __init__(self, channels: int, duration: float, alias: str, filepath: Optional[Union[str, Path]] = None,
+                 noise: Optional[Union[str, float]] = None, ref_db: Optional[float] = config.DEFAULT_REF_DB,
+                 sample_rate: Optional[int] = config.SAMPLE_RATE, clip: Optional[np.ndarray] = None, **kwargs):
+        for name, val in (("channels", channels), ("sample_rate", sample_rate), ("duration", duration)):
+            if not isinstance(val, (int, float, np.integer, np.floating)) or isinstance(val, bool):
+                raise TypeError(f"Expected a numeric input for {name}, but got {type(val)}")
+            if val < 0:
+                raise ValueError(f"Expected a positive numeric input for {name}, but got {val}")
+        self.channels, self.sample_rate, self.duration, self.alias = int(channels), int(sample_rate), float(duration), alias
+        self.clip = None if clip is None else np.atleast_2d(np.asarray(clip, dtype=np.float32))
+        have_file = filepath is not None or clip is not None
+        if noise is None and have_file:
+            self.filepath, self.beta = (Path(filepath) if filepath is not None else None), None
+        elif noise is not None and not have_file:
+            self.filepath, self.beta = None, _parse_beta(noise)
+        elif noise is not None and have_file:
+            raise AttributeError("Only one of `noise` or `filepath` should be provided.")
+        else:
+            raise AttributeError("One of `noise` or `filepath` must be provided")
+        bad = set(kwargs) - {"fmin", "seed"}
+        if bad:
+            raise AttributeError(f"`{sorted(bad)[0]}` is not a valid keyword argument for `powerlaw_psd_gaussian`")
+        self.noise_kwargs = kwargs
+        if not isinstance(ref_db, (int, float, np.integer, np.floating)) or -ref_db < 0:
+            raise ValueError(f"Expected a negative noise floor in dB, but got {ref_db}")
+        self.ref_db = ref_db
+        self.audio: Optional[np.ndarray] = None
+        self._device = None
+        self.device_shape = None
+
+    @property
+    def is_audio_loaded(self) -> bool:
+        return self.audio is not None and valid_audio(self.audio)
+
+    def _decode(self) -> np.ndarray:
+        if self.clip is not None:
+            return self.clip
+        from scipy.io import wavfile  # WAV only: decoding/resampling other formats is out of scope here
+
+        sr, data = wavfile.read(self.filepath)
+        if sr != self.sample_rate:
+            raise ValueError(f"Ambience file is {sr} Hz but the Ambience wants {self.sample_rate} Hz (resample upstream)")
+        data = data.astype(np.float32) / (np.iinfo(data.dtype).max if np.issubdtype(data.dtype, np.integer) else 1.0)
+        return np.atleast_2d(data.T if data.ndim == 2 else data)
+
+    def load_ambience_device(self, renderer=None, ignore_cache: bool = False, normalize: bool = True):
+        """(channels*samples) float32 device buffer of the ambience; cached."""
+        if self._device is not None and not ignore_cache:
+            return self._device
+        r = renderer or _renderer()
+        total = round(self.duration * self.sample_rate)
+        if self.beta is not None:
+            if self.beta == "gaussian":
+                dev = r.mem.upload(np.random.normal(0, 1, (self.channels, total)).astype(np.float32).reshape(-1))
+            else:
+                dev = powerlaw_noise_device(r, self.beta, self.channels, total, **self.noise_kwargs)
+        else:
+            src = self._decode()
+            if src.shape[0] != self.channels:
+                row = 0 if src.shape[0] == 1 else int(np.random.choice(src.shape[0]))  # ambience.py:183-192
+                src = np.repeat(src[row: row + 1], self.channels, axis=0)
+            dev = r.mem.empty(self.channels * total)
+            for c in range(self.channels):  # np.tile along time (ambience.py:204-208)
+                one = r.mem.upload(np.ascontiguousarray(src[c]))
+                r.lib.call("al_wrap_copy", r.mem.ptr(one), src.shape[1], r.mem.ptr(dev) + 4 * c * total, total, r.mem.stream())
+            r.mem.synchronize()
+        if normalize:
+            peak_normalize_rows_device(r, dev, self.channels, total)
+        self._device, self.device_shape = dev, (self.channels, total)
+        return dev
+
+    def load_ambience(self, ignore_cache: Optional[bool] = False, normalize: Optional[bool] = True) -> np.ndarray:
+        """(channels, samples) array; computed on the GPU, cached in ``self.audio`` (reference ambience.py:142-217)."""
+        if self.is_audio_loaded and not ignore_cache:
+            return self.audio
+        r = _renderer()
+        dev = self.load_ambience_device(r, ignore_cache=True, normalize=bool(normalize))
+        c, n = self.device_shape
+        self.audio = r.mem.download(dev)[: c * n].reshape(c, n).astype(np.float64)
+        return self.audio
+
+    def to_dict(self) -> dict:
+        return dict(alias=self.alias, beta=self.beta, filepath=str(self.filepath) if self.filepath is not None else None,
+                    channels=self.channels, sample_rate=self.sample_rate, duration=self.duration, ref_db=self.ref_db,
+                    noise_kwargs=self.noise_kwargs)
+
+    @classmethod
+    def from_dict(cls, input_dict: dict[str, Any]):
+        for k in ["alias", "filepath", "duration", "ref_db", "beta", "channels"]:
+            if k not in input_dict:
+                raise KeyError(f"Missing key: '{k}'")
+        return cls(channels=input_dict["channels"], sample_rate=input_dict["sample_rate"], alias=input_dict["alias"],
+                   filepath=input_dict["filepath"], duration=input_dict["duration"], noise=input_dict["beta"],
+                   ref_db=input_dict["ref_db"], **input_dict["noise_kwargs"])
+
+    def __eq__(self, other: Any) -> bool:
+        return isinstance(other, Ambience) and self.to_dict() == other.to_dict()
+
+    def __str__(self) -> str:
+        return f"'Ambience' with alias '{self.alias}' (currently {'loaded' if self.audio is not None else 'unloaded'})."

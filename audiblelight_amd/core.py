@@ -1,0 +1,159 @@
+"""Minimal Scene / Event / WorldState stand-ins with the attribute surface the synthesis path uses.
+
+The reference's ``Scene`` (audiblelight/core.py), ``Event`` (audiblelight/event.py) and ``WorldState``
+(audiblelight/worldstate.py) do placement, ray tracing and file decoding, which are out of scope
+here.  These classes carry exactly the attributes listed in SURVEY.md 8a A15,
+so a scene can be described from arrays already in memory (clips + IR tensors) and rendered with
+``Scene.generate()``; objects of the real AudibleLight classes work with the same functions.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import config
+from .utils import LazyAudioDict, tiny, valid_audio
+
+
+class Event:
+    """An audio event: a mono clip, its emitters (IR columns), timing and level (event.py:31-191)."""
+
+    def __init__(self, alias: str, audio: np.ndarray, sample_rate: int = config.SAMPLE_RATE, snr: float = 15.0,
+                 scene_start: float = 0.0, n_emitters: int = 1, is_moving: Optional[bool] = None,
+                 augmentations: Sequence = (), ref_ir_channel: Optional[int] = None,
+                 direct_path_time_ms: Optional[Sequence[float]] = None, class_label: Optional[str] = None):
+        audio = np.asarray(audio)
+        if audio.ndim != 1:
+            raise ValueError("Event audio must be mono (1-D)")
+        self.alias = alias
+        self.sample_rate = int(sample_rate)
+        self._raw = np.ascontiguousarray(audio, dtype=np.float32)
+        self.snr = float(snr)
+        self.scene_start = float(scene_start)
+        self.duration = len(self._raw) / self.sample_rate
+        self.scene_end = self.scene_start + self.duration
+        self.n_emitters = int(n_emitters)
+        self.is_moving = bool(self.n_emitters > 1 if is_moving is None else is_moving)
+        self.augmentations: List = list(augmentations)
+        self.ref_ir_channel = ref_ir_channel
+        self.direct_path_time_ms = direct_path_time_ms
+        self.class_label = class_label
+        self.audio: Optional[np.ndarray] = None
+        self.spatial_audio = LazyAudioDict()
+        self._spatial_audio_padded = LazyAudioDict()
+        self._spatial_audio_dry: Dict[str, np.ndarray] = OrderedDict()
+        self._spatial_audio_dry_padded: Dict[str, np.ndarray] = OrderedDict()
+
+    def __len__(self) -> int:
+        return self.n_emitters
+
+    @property
+    def is_audio_loaded(self) -> bool:
+        return self.audio is not None
+
+    def register_augmentations(self, augmentations) -> None:
+        """Add FX and drop every cached render (event.py:739-782)."""
+        self.augmentations.extend(augmentations if isinstance(augmentations, (list, tuple)) else [augmentations])
+        self.clear_audio()
+
+    def clear_augmentations(self) -> None:
+        self.augmentations = []
+        self.clear_audio()
+
+    def clear_audio(self) -> None:
+        self.audio = None
+        self.spatial_audio = LazyAudioDict()
+        self._spatial_audio_padded = LazyAudioDict()
+        self._spatial_audio_dry = OrderedDict()
+        self._spatial_audio_dry_padded = OrderedDict()
+
+    def load_audio(self, ignore_cache: Optional[bool] = False, normalize: Optional[bool] = True) -> np.ndarray:
+        """Clip after the FX chain and peak normalisation (event.py:496-539); cached in ``self.audio``."""
+        if self.is_audio_loaded and not ignore_cache:
+            return self.audio
+        out = self._raw.copy()
+        for aug in self.augmentations:
+            out = aug(out)
+        if normalize:
+            from . import augmentation
+
+            out = augmentation.peak_normalize(out)
+        valid_audio(out)
+        self.audio = out
+        return self.audio
+
+    def to_dict(self) -> dict:
+        return dict(alias=self.alias, sample_rate=self.sample_rate, snr=self.snr, scene_start=self.scene_start,
+                    scene_end=self.scene_end, duration=self.duration, n_emitters=self.n_emitters,
+                    is_moving=self.is_moving, class_label=self.class_label,
+                    augmentations=[a.to_dict() for a in self.augmentations if hasattr(a, "to_dict")])
+
+
+class MicArray:
+    """Capsule count holder (micarrays.py:36-162): only ``n_capsules`` / ``n_listeners`` matter to the path."""
+
+    def __init__(self, alias: str, n_capsules: int):
+        self.alias, self.n_capsules, self.n_listeners = alias, int(n_capsules), int(n_capsules)
+
+
+class StaticIRState:
+    """WorldState stand-in holding precomputed IRs: {mic: (C, N_emitters_total, L)} (worldstate.py:360-370)."""
+
+    name = "static"
+
+    def __init__(self, irs: Dict[str, np.ndarray]):
+        self._irs = OrderedDict((k, np.asarray(v)) for k, v in irs.items())
+        self.microphones = OrderedDict((k, MicArray(k, v.shape[0])) for k, v in self._irs.items())
+
+    @property
+    def irs(self):
+        return self._irs
+
+    @property
+    def num_emitters(self) -> int:
+        return next(iter(self._irs.values())).shape[1] if self._irs else 0
+
+    def get_irs(self):
+        return self._irs
+
+    def simulate(self) -> None:  # IRs are given, nothing to trace
+        return None
+
+
+class Scene:
+    """Container with the attributes the synthesis functions read (core.py:131-251) and ``generate``."""
+
+    def __init__(self, duration: float, state: StaticIRState, sample_rate: int = config.SAMPLE_RATE,
+                 ref_db: float = config.DEFAULT_REF_DB):
+        self.duration, self.state, self.sample_rate, self.ref_db = float(duration), state, int(sample_rate), ref_db
+        self.events: "OrderedDict[str, Event]" = OrderedDict()
+        self.ambience: "OrderedDict[str, object]" = OrderedDict()
+        self.audio: Dict[str, np.ndarray] = OrderedDict()
+
+    def add_event(self, event: Event) -> Event:
+        if event.alias in self.events:
+            raise KeyError(f"Event with alias {event.alias} already exists")
+        self.events[event.alias] = event
+        return event
+
+    def add_ambience(self, ambience) -> None:
+        self.ambience[ambience.alias] = ambience
+
+    def generate(self, output_dir=None, audio: bool = True, audio_fname: str = "audio_out") -> Dict[str, np.ndarray]:
+        """Render every event and mix the scene (core.py:1789-1874, audio branch); writes float32 WAV
+        files ``<audio_fname>_<mic>.wav`` when ``output_dir`` is given."""
+        from . import synthesize
+
+        synthesize.render_audio_for_all_scene_events(self)
+        synthesize.generate_scene_audio_from_events(self)
+        if output_dir is not None and audio:
+            import os
+
+            from scipy.io import wavfile
+
+            os.makedirs(output_dir, exist_ok=True)
+            for mic, buf in self.audio.items():
+                wavfile.write(os.path.join(output_dir, f"{audio_fname}_{mic}.wav"), self.sample_rate, buf.T)
+        return self.audio

@@ -19,6 +19,7 @@
 
 #include "../../include/audiblelight_hip.h"
 #include "al_fft.h"
+#include "al_bigfft.h"
 
 namespace al {
 
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) b.emitter_gain[n] = (float)((double)b.n_capsules / acc);
+  if (lane == 0) b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)b.n_capsules / acc);
 }
 
 // ------------------------------------------------------------------ 3. signal block spectra
@@ -414,45 +415,166 @@ __global__ __launch_bounds__(256) void k_row_stats(const float *x, int64_t cols,
   const int chunk = blockIdx.x, r = blockIdx.y;
   const int64_t lo = (int64_t)chunk * ROW_CHUNK, hi = lo + ROW_CHUNK < cols ? lo + ROW_CHUNK : cols;
   const float *row = x + (int64_t)r * cols;
-  float asum = 0.f, amax = 0.f, bad = 0.f;
+  float asum = 0.f, amax = 0.f, bad = 0.f, sq = 0.f;
   for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
     const float v = row[i];
     asum += fabsf(v);
     amax = fmaxf(amax, fabsf(v));
     bad += isfinite(v) ? 0.f : 1.f;
+    sq = fmaf(v, v, sq);
   }
   block_reduce3(asum, amax, bad, red, threadIdx.x, 256);
+  __syncthreads();
+  float z0 = 0.f, z1 = 0.f;
+  block_reduce3(sq, z0, z1, red, threadIdx.x, 256);
   if (threadIdx.x == 0) {
     float *pp = partials + 4 * ((int64_t)r * gridDim.x + chunk);
     pp[0] = asum;
     pp[1] = amax;
     pp[2] = bad;
-    pp[3] = 0.f;
+    pp[3] = sq;
   }
 }
 
 __global__ __launch_bounds__(64) void k_row_stats_final(const float *partials, int nchunks, double *out) {
   const int r = blockIdx.x, lane = threadIdx.x;
   const float *pp = partials + 4 * (int64_t)r * nchunks;
-  double sum = 0.0, bad = 0.0;
+  double sum = 0.0, bad = 0.0, sq = 0.0;
   float mx = 0.f;
   for (int i = lane; i < nchunks; i += 64) {
     sum += (double)pp[4 * i];
     mx = fmaxf(mx, pp[4 * i + 1]);
     bad += (double)pp[4 * i + 2];
+    sq += (double)pp[4 * i + 3];
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) {
     sum += __shfl_down(sum, off, 64);
     mx = fmaxf(mx, __shfl_down(mx, off, 64));
     bad += __shfl_down(bad, off, 64);
+    sq += __shfl_down(sq, off, 64);
   }
   if (lane == 0) {
     out[4 * r + 0] = sum;
     out[4 * r + 1] = (double)mx;
     out[4 * r + 2] = bad;
-    out[4 * r + 3] = 0.0;
+    out[4 * r + 3] = sq;
   }
+}
+
+// ------------------------------------------------------------------ sample-wise clip operations (A13/A14)
+__device__ __forceinline__ float fade_in_curve(int shape, float r) {  // augmentation.py:1490-1508
+  switch (shape) {
+    case AL_FADE_EXPONENTIAL: return exp2f(r - 1.f) * r;
+    case AL_FADE_LOGARITHMIC: return log10f(0.1f + r) + 1.f;
+    case AL_FADE_QUARTER_SINE: return sinpif(0.5f * r);
+    case AL_FADE_HALF_SINE: return 0.5f * sinpif(r - 0.5f) + 0.5f;
+    default: return r;
+  }
+}
+__device__ __forceinline__ float fade_out_curve(int shape, float r) {  // augmentation.py:1510-1528
+  switch (shape) {
+    case AL_FADE_EXPONENTIAL: return exp2f(-r) * (1.f - r);
+    case AL_FADE_LOGARITHMIC: return log10f(1.1f - r) + 1.f;
+    case AL_FADE_QUARTER_SINE: return sinpif(0.5f * r + 0.5f);
+    case AL_FADE_HALF_SINE: return 0.5f * sinpif(r + 0.5f) + 0.5f;
+    default: return 1.f - r;
+  }
+}
+
+struct FxArgs {
+  int op;
+  float p0;
+  int n_in, n_out, shape_in, shape_out;
+};
+
+__global__ __launch_bounds__(256) void k_fx_pointwise(const float *src, float *dst, int64_t n, FxArgs a) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    float x = src[a.op == AL_FX_REVERSE ? n - 1 - t : t];
+    switch (a.op) {
+      case AL_FX_GAIN: x *= a.p0; break;
+      case AL_FX_INVERT: x = -x; break;
+      case AL_FX_CLIP: x = fminf(fmaxf(x, -a.p0), a.p0); break;
+      case AL_FX_TANH: x = tanhf(a.p0 * x); break;
+      case AL_FX_BITCRUSH: x = rintf(x * a.p0) / a.p0; break;
+      case AL_FX_FADE: {
+        float g = 1.f;
+        if (a.n_in > 0 && a.shape_in != AL_FADE_NONE && t < a.n_in) {
+          const float r = a.n_in > 1 ? (float)t / (float)(a.n_in - 1) : 0.f;  // np.linspace(0, 1, n_in)
+          g *= fminf(fmaxf(fade_in_curve(a.shape_in, r), 0.f), 1.f);
+        }
+        if (a.n_out > 0 && a.shape_out != AL_FADE_NONE && t >= n - a.n_out) {
+          const float r = a.n_out > 1 ? (float)(t - (n - a.n_out)) / (float)(a.n_out - 1) : 0.f;
+          g *= fminf(fmaxf(fade_out_curve(a.shape_out, r), 0.f), 1.f);
+        }
+        x *= g;
+      } break;
+      case AL_FX_PREEMPH: {
+        if (t == 0) x = x + (2.f * x - (n > 1 ? src[1] : x));
+        else x = fmaf(-a.p0, src[t - 1], x);
+      } break;
+      default: break;
+    }
+    dst[t] = x;
+  }
+}
+
+// y[n] = x[n] + c*y[n-1] minus the extrapolation correction: one workgroup, each thread owns a
+// contiguous run; carries are chained by thread 0 (1024 runs), then folded back in.
+__global__ __launch_bounds__(1024) void k_fx_deemph(const float *src, float *dst, int64_t n, float c) {
+  __shared__ float tail[1024], decay[1024], carry[1024];
+  const int tid = threadIdx.x;
+  const int64_t run = (n + 1023) / 1024;
+  const int64_t lo = (int64_t)tid * run, hi = lo + run < n ? lo + run : n;
+  float y = 0.f, d = 1.f;
+  for (int64_t t = lo; t < hi; ++t) {
+    y = fmaf(c, y, src[t]);
+    d *= c;
+    dst[t] = y;
+  }
+  tail[tid] = y;
+  decay[tid] = d;
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (int i = 0; i < 1024; ++i) {
+      carry[i] = acc;  // state entering run i
+      acc = fmaf(decay[i], acc, tail[i]);
+    }
+  }
+  __syncthreads();
+  const float x0 = src[0], x1 = n > 1 ? src[1] : src[0];
+  const float corr = ((2.f - c) * x0 - x1) / (3.f - c);
+  float pw = c;                      // c^(t - lo + 1)
+  float cn = powf(c, (float)lo);     // c^t
+  const float cin = carry[tid];
+  for (int64_t t = lo; t < hi; ++t) {
+    dst[t] = fmaf(cin, pw, dst[t]) - corr * cn;
+    pw *= c;
+    cn *= c;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_frame_shuffle(const float *src, float *dst, int64_t n, int frame_len,
+                                                       int row_len, const int32_t *rows, int n_rows) {
+  const int64_t total = (int64_t)n_rows * row_len;
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    const int64_t u = t % total;
+    const int q = (int)(u / row_len), j = (int)(u - (int64_t)q * row_len);
+    const int r = rows[2 * q], mode = rows[2 * q + 1];
+    const int jj = mode == 2 ? row_len - 1 - j : j;
+    dst[t] = mode == 1 ? 0.f : src[r + (int64_t)frame_len * jj];
+  }
+}
+
+__global__ __launch_bounds__(256) void k_scale_matrix_rows(float *x, int64_t cols, const float *scale) {
+  const float s = scale[blockIdx.y];
+  float *row = x + (int64_t)blockIdx.y * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cols; i += (int64_t)gridDim.x * 256) row[i] *= s;
+}
+
+__global__ __launch_bounds__(256) void k_wrap_copy(const float *src, int64_t m, float *dst, int64_t n) {
+  for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) dst[t] = src[t % m];
 }
 
 }  // namespace al
@@ -620,6 +742,143 @@ int al_row_stats(const float *x, int32_t rows, int64_t cols, float *partials, do
   if (int rc = check_launch("k_row_stats")) return rc;
   hipLaunchKernelGGL(al::k_row_stats_final, dim3(rows), dim3(64), 0, (hipStream_t)stream, partials, nchunks, out);
   return check_launch("k_row_stats_final");
+}
+
+int al_fx_apply(int op, const float *src, float *dst, int64_t n, const float *params, const int32_t *iparams,
+                al_stream_t stream) {
+  if (!src || !dst || n <= 0) return fail(AL_E_BADARG, "bad fx arguments");
+  if (op < AL_FX_GAIN || op > AL_FX_DEEMPH) return fail(AL_E_UNSUPPORTED, "unknown fx op");
+  const bool out_of_place = (op == AL_FX_REVERSE || op == AL_FX_PREEMPH || op == AL_FX_DEEMPH);
+  if (out_of_place && src == dst) return fail(AL_E_BADARG, "this fx op needs dst != src");
+  if ((op == AL_FX_PREEMPH || op == AL_FX_DEEMPH) && n < 2) return fail(AL_E_BADARG, "emphasis filters need n >= 2");
+  al::FxArgs a{op, params ? params[0] : 0.f, 0, 0, AL_FADE_NONE, AL_FADE_NONE};
+  if (op == AL_FX_FADE) {
+    if (!iparams) return fail(AL_E_BADARG, "fade needs iparams");
+    a.n_in = iparams[0]; a.n_out = iparams[1]; a.shape_in = iparams[2]; a.shape_out = iparams[3];
+  }
+  if (op == AL_FX_DEEMPH) {
+    hipLaunchKernelGGL(al::k_fx_deemph, dim3(1), dim3(1024), 0, (hipStream_t)stream, src, dst, n, a.p0);
+    return check_launch("k_fx_deemph");
+  }
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_fx_pointwise, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n, a);
+  return check_launch("k_fx_pointwise");
+}
+
+int al_fx_frame_shuffle(const float *src, float *dst, int64_t n, int32_t frame_len, int32_t row_len,
+                        const int32_t *rows, int32_t n_rows, al_stream_t stream) {
+  if (!src || !dst || !rows || n <= 0 || frame_len <= 0 || row_len <= 0 || n_rows <= 0 || src == dst)
+    return fail(AL_E_BADARG, "bad frame_shuffle arguments");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_frame_shuffle, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, src, dst, n, frame_len, row_len, rows, n_rows);
+  return check_launch("k_frame_shuffle");
+}
+
+// ---- arbitrary-length inverse real FFT (ambience)
+namespace {
+struct BigPlan {
+  int64_t len;       // complex transform length (n/2 for even n, n for odd n)
+  bool bluestein;
+  int64_t L;         // power-of-two Bluestein length (0 if unused)
+};
+
+int64_t strip_small_factors(int64_t m) {
+  for (int f : {2, 3, 5, 7})
+    while (m % f == 0) m /= f;
+  return m;
+}
+
+BigPlan big_plan(int64_t n) {
+  BigPlan p;
+  p.len = (n & 1) ? n : n / 2;
+  p.bluestein = strip_small_factors(p.len) != 1;
+  p.L = 0;
+  if (p.bluestein) {
+    p.L = 1;
+    while (p.L < 2 * p.len - 1) p.L <<= 1;
+  }
+  return p;
+}
+
+// Stockham passes over `rows` series of `len` points; returns the buffer holding the result.
+float2 *big_fft(float2 *a, float2 *b, int rows, int64_t len, int dir, hipStream_t stream) {
+  int64_t ns = 1, rest = len;
+  float2 *in = a, *out = b;
+  while (rest > 1) {
+    int r = 0;
+    for (int cand : {4, 2, 3, 5, 7})
+      if (rest % cand == 0) { r = cand; break; }
+    const dim3 grid((unsigned)((len / r + 255) / 256), rows);
+    switch (r) {
+      case 2: hipLaunchKernelGGL((al::k_big_pass<2>), grid, dim3(256), 0, stream, in, out, len, ns, dir); break;
+      case 3: hipLaunchKernelGGL((al::k_big_pass<3>), grid, dim3(256), 0, stream, in, out, len, ns, dir); break;
+      case 4: hipLaunchKernelGGL((al::k_big_pass<4>), grid, dim3(256), 0, stream, in, out, len, ns, dir); break;
+      case 5: hipLaunchKernelGGL((al::k_big_pass<5>), grid, dim3(256), 0, stream, in, out, len, ns, dir); break;
+      default: hipLaunchKernelGGL((al::k_big_pass<7>), grid, dim3(256), 0, stream, in, out, len, ns, dir); break;
+    }
+    ns *= r;
+    rest /= r;
+    float2 *t = in; in = out; out = t;
+  }
+  return in;
+}
+}  // namespace
+
+int64_t al_noise_workspace_floats(int32_t rows, int64_t n) {
+  if (rows <= 0 || n <= 0) return 0;
+  const BigPlan p = big_plan(n);
+  const int64_t per = p.bluestein ? p.L : p.len;
+  return 2 * (2 * (int64_t)rows * per) + (p.bluestein ? 2 * 2 * p.L + 2 * (int64_t)rows * p.len : 0);
+}
+
+int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t rows, int64_t n, float inv_sigma,
+                   float *out, float *workspace, al_stream_t stream) {
+  if (!zr || !zi || !shape || !out || !workspace || rows <= 0 || n <= 0) return fail(AL_E_BADARG, "bad noise arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const BigPlan p = big_plan(n);
+  const int64_t per = p.bluestein ? p.L : p.len;
+  float2 *a = reinterpret_cast<float2 *>(workspace);
+  float2 *b = a + (int64_t)rows * per;
+  const dim3 g_len((unsigned)((p.len + 255) / 256), rows);
+  const float2 *z;
+  if (!p.bluestein) {
+    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, shape, n, a);
+    z = big_fft(a, b, rows, p.len, +1, st);
+  } else {
+    float2 *kern = b + (int64_t)rows * per;           // 2 * L: chirp kernel and its ping-pong partner
+    float2 *x = kern + 2 * p.L;                        // rows * len: packed spectrum / transform result
+    const dim3 g_L((unsigned)((p.L + 255) / 256), rows), g_L1((unsigned)((p.L + 255) / 256), 1);
+    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, shape, n, x);
+    hipLaunchKernelGGL(al::k_blue_kernel, g_L1, dim3(256), 0, st, p.len, p.L, +1, kern);
+    const float2 *kspec = big_fft(kern, kern + p.L, 1, p.L, -1, st);
+    hipLaunchKernelGGL(al::k_blue_pre, g_L, dim3(256), 0, st, (const float2 *)x, p.len, p.L, +1, a);
+    float2 *A = big_fft(a, b, rows, p.L, -1, st);
+    hipLaunchKernelGGL(al::k_blue_mul, g_L, dim3(256), 0, st, A, kspec, p.L);
+    float2 *other = (A == a) ? b : a;
+    const float2 *y = big_fft(A, other, rows, p.L, +1, st);
+    hipLaunchKernelGGL(al::k_blue_post, g_len, dim3(256), 0, st, y, p.len, p.L, +1, x);
+    z = x;
+  }
+  hipLaunchKernelGGL(al::k_noise_unpack, g_len, dim3(256), 0, st, z, n, inv_sigma / (float)p.len, out);
+  return check_launch("al_noise_irfft");
+}
+
+int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream) {
+  if (!x || !scale || rows <= 0 || cols <= 0) return fail(AL_E_BADARG, "bad scale_matrix_rows arguments");
+  const int64_t blocks = (cols + 255) / 256;
+  hipLaunchKernelGGL(al::k_scale_matrix_rows, dim3((unsigned)(blocks < 2048 ? blocks : 2048), rows), dim3(256), 0,
+                     (hipStream_t)stream, x, cols, scale);
+  return check_launch("k_scale_matrix_rows");
+}
+
+int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream) {
+  if (!src || !dst || m <= 0 || n <= 0 || src == dst) return fail(AL_E_BADARG, "bad wrap_copy arguments");
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_wrap_copy, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0,
+                     (hipStream_t)stream, src, m, dst, n);
+  return check_launch("k_wrap_copy");
 }
 
 }  // extern "C"

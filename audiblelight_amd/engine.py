@@ -117,7 +117,7 @@ class Renderer:
         return host
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-                chunk_events: Optional[int] = None) -> "PreparedBatch":
+                chunk_events: Optional[int] = None, normalize_irs: bool = True) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over one reused spectra workspace."""
@@ -145,27 +145,32 @@ class Renderer:
             n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
             n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
-            yspec_block0=c["yspec_block0"], **ptrs) for c in chunks]
+            yspec_block0=c["yspec_block0"], flags=0 if normalize_irs else _hip.FLAG_NO_IR_NORM, **ptrs)
+            for c in chunks]
         return PreparedBatch(self, plan, bufs, descs)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-               stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None) -> RenderResult:
+               stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None,
+               normalize_irs: bool = True) -> RenderResult:
         """prepare + run stages 1-6 for one batch."""
-        return self.prepare(plan, clips, irs, ir_strides, chunk_events).run(stages)
+        return self.prepare(plan, clips, irs, ir_strides, chunk_events, normalize_irs).run(stages)
 
-    def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()) -> "PreparedMix":
+    def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = (), scene=None) -> "PreparedMix":
+        """``scene``: an existing (C*T) device buffer to accumulate into (else a new buffer is made)."""
         mem = self.mem
         n = mix.n_capsules * mix.n_samples
         tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
                                         mix.slot_count, mix.slot_rows, mix.slot_event)]
-        scene = mem.empty(n)
+        accumulate = bool(ambience) or scene is not None
+        zero_first = scene is None and bool(ambience)
+        scene = mem.empty(n) if scene is None else scene
         p = mem.ptr
         desc = _hip.AlMix(n_capsules=mix.n_capsules, n_samples=mix.n_samples, tile=mix.tile, n_tiles=mix.n_tiles,
-                          accumulate=1 if ambience else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
+                          accumulate=1 if accumulate else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
                           slot_src=p(tabs[2]), slot_len=p(tabs[3]), slot_start=p(tabs[4]), slot_count=p(tabs[5]),
                           slot_rows=p(tabs[6]), slot_event=p(tabs[7]), spatial=p(result.spatial),
                           event_scale=p(result.event_scale), scene=p(scene))
-        return PreparedMix(self, mix, desc, scene, list(ambience), tabs + [result])
+        return PreparedMix(self, mix, desc, scene, list(ambience), tabs + [result], zero_first)
 
     # -- A11
     def mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()):
@@ -211,15 +216,17 @@ class PreparedBatch:
 
 
 class PreparedMix:
-    def __init__(self, renderer: Renderer, mix: MixPlan, desc: _hip.AlMix, scene, ambience, keep):
+    def __init__(self, renderer: Renderer, mix: MixPlan, desc: _hip.AlMix, scene, ambience, keep, zero_first=False):
         self.renderer, self.mix, self.desc, self.scene, self.ambience, self.keep = renderer, mix, desc, scene, ambience, keep
+        self.zero_first = zero_first
 
     def run(self):
         mem, lib = self.renderer.mem, self.renderer.lib
         stream = mem.stream()
         n = self.mix.n_capsules * self.mix.n_samples
         if self.ambience:
-            self.scene.zero_() if hasattr(self.scene, "zero_") else self.scene.fill(0)
+            if self.zero_first:
+                self.scene.zero_() if hasattr(self.scene, "zero_") else self.scene.fill(0)
             for noise, a_dev in self.ambience:
                 lib.call("al_axpy", mem.ptr(self.scene), mem.ptr(noise), mem.ptr(a_dev), n, stream)
         lib.call("al_mixdown", ct.byref(self.desc), stream)

@@ -54,6 +54,7 @@ class EventSpec:
     duration: Optional[float] = None   # seconds, Event.duration (moving events)
     gain: float = 1.0            # scalar folded into the clip (peak normalisation, FX gain/polarity)
     ref_db: float = config.DEFAULT_REF_DB
+    stft_len: Optional[int] = None     # samples the STFT frame count is taken from (default n_samples)
 
 
 @dataclass
@@ -186,7 +187,7 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
             if sp.duration is None:
                 raise ValueError("moving events need Event.duration")
             w = generate_interpolation_matrix(np.linspace(0, sp.duration, sp.n_emitters), sample_rate, hop)
-            n_frames = min(stft_frame_count(La, hop), w.shape[0])
+            n_frames = min(stft_frame_count(sp.stft_len or La, hop), w.shape[0])
             valid = min(La, max(n_frames * hop - win, 0))
             ev["n_streams"] = sp.n_emitters
             for l in range(sp.n_emitters):

@@ -1,0 +1,389 @@
+"""MI355X implementation of AudibleLight's synthesis functions, same names and contracts.
+
+Mirror of ``audiblelight/synthesize.py`` (reference lines cited per function).  Every function
+that touches samples runs on the GPU through the C ABI of include/audiblelight_hip.h; there is
+no CPU fallback (a missing extension or GPU raises).  Results are written onto the Scene/Event
+objects exactly where the reference writes them; arrays that stay in HBM are exposed through
+``utils.LazyAudioDict`` and are copied to the host as ``np.ndarray`` on first access.
+
+Drop-in use with the real AudibleLight package: ``audiblelight_amd.dropin.install()``.
+"""
+from __future__ import annotations
+
+import logging
+from time import time
+from typing import Dict, List, Optional
+
+import numpy as np
+
+from . import config, engine
+from . import plan as planning
+from .plan import generate_interpolation_matrix  # noqa: F401  (same public name as the reference)
+from .utils import LazyAudioDict, as_lazy, pad_or_truncate_audio, tiny, valid_audio, validate_shape
+
+logger = logging.getLogger("audiblelight_amd")
+
+_renderer: Optional[engine.Renderer] = None
+
+
+def get_renderer() -> engine.Renderer:
+    """Process-wide renderer on the current device (created on first use; raises without a GPU)."""
+    global _renderer
+    if _renderer is None:
+        _renderer = engine.Renderer()
+    return _renderer
+
+
+def set_renderer(renderer: Optional[engine.Renderer]) -> None:
+    global _renderer
+    _renderer = renderer
+
+
+# ----------------------------------------------------------------------------- scalar helpers
+def apply_snr(x: np.ndarray, snr) -> np.ndarray:
+    """Scale to a maximum SNR: ``x * snr / max(|x|, 1e-15)`` (reference synthesize.py:40-49).
+
+    Host utility kept for API compatibility; the render path fuses it into the level law on device.
+    """
+    return x * snr / np.abs(x).max(initial=1e-15)
+
+
+def db_to_multiplier(db, x) -> float:
+    """``10^(db/20) / (x + tiny(x))`` (reference synthesize.py:52-68)."""
+    return 10 ** (db / 20) / (x + tiny(x))
+
+
+# ----------------------------------------------------------------------------- convolutions
+def time_invariant_convolution(audio: np.ndarray, ir: np.ndarray) -> np.ndarray:
+    """Full linear convolution of a mono clip with each IR channel -> (C, La + Lir - 1).
+
+    Reference synthesize.py:71-106 (scipy.signal.fftconvolve along axis 0).  Here: partitioned
+    overlap-save FFT convolution on the GPU.
+    """
+    if audio.ndim != 1:
+        raise ValueError(f"Only mono input is supported, but got {audio.ndim} dimensions!")
+    if ir.ndim != 2:
+        raise ValueError(f"Expected shape of IR should be (n_samples, n_channels), but got ({ir.shape}) instead")
+    n_ir, n_ch = ir.shape
+    n_out = audio.shape[0] + n_ir - 1
+    clip = np.zeros(n_out, dtype=np.float32)
+    clip[: audio.shape[0]] = audio
+    r = get_renderer()
+    pl = planning.plan_batch([planning.EventSpec(n_samples=n_out, n_emitters=1, snr=1.0)], n_ch, n_ir, 1.0)
+    res = r.render(pl, [clip], np.ascontiguousarray(ir.T)[:, None, :], normalize_irs=False)
+    return res.raw_spatial(0).astype(np.float64)
+
+
+def time_variant_convolution(irs: np.ndarray, event, fft_size=config.FFT_SIZE, win_size=config.WIN_SIZE,
+                             hop_size=config.HOP_SIZE) -> np.ndarray:
+    """Time-variant convolution of a moving event: (C, N, L) IRs -> (C, n_frames*hop - win).
+
+    Reference synthesize.py:277-310 (STFT-domain convolution with linear IR cross-fades).  Computed
+    here in the mathematically identical envelope form ("Moving events").
+    """
+    audio = np.asarray(event.load_audio(), dtype=np.float32)
+    fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
+    if min(fft_size, win_size, hop_size) <= 0:
+        raise ValueError("fft_size, win_size and hop_size must be positive")
+    n_ch, n_irs, n_ir = irs.shape
+    # the reference returns n_frames*hop - win samples, up to `hop` more than the clip: render into a
+    # clip extended by win zeros while counting STFT frames on the original length
+    clip = np.zeros(len(audio) + win_size, dtype=np.float32)
+    clip[: len(audio)] = audio
+    spec = planning.EventSpec(n_samples=len(clip), n_emitters=n_irs, snr=1.0, is_moving=True,
+                              duration=event.duration, stft_len=len(audio))
+    pl = planning.plan_batch([spec], n_ch, n_ir, event.sample_rate, hop=hop_size, win=win_size, fft_size=fft_size)
+    res = get_renderer().render(pl, [clip], irs, normalize_irs=False)
+    return res.raw_spatial(0)[:, : int(pl.events["valid_len"][0])].astype(np.float64)
+
+
+def normalize_irs(irs: np.ndarray) -> np.ndarray:
+    """Divide by the mean (axis -2) of the L2 norms (axis -1) (reference synthesize.py:404-428).
+
+    Row energies are reduced on the GPU (al_row_stats) and each row is rescaled on the GPU.
+    """
+    arr = np.asarray(irs)
+    if arr.ndim < 2:
+        raise ValueError("normalize_irs expects at least a 2-D array")
+    cols, rows = arr.shape[-1], arr.shape[-2]
+    flat = np.ascontiguousarray(arr.reshape(-1, cols), dtype=np.float32)
+    r = get_renderer()
+    dev = r.mem.upload(flat.reshape(-1))
+    stats = r.mem.download(r.row_stats(dev, flat.shape[0], cols)).reshape(-1, 4)[: flat.shape[0]]
+    e = np.sqrt(stats[:, 3]).reshape(-1, rows)
+    e = e + tiny(e)
+    scale = np.repeat(1.0 / e.mean(axis=1), rows).astype(np.float32)
+    s_dev = r.mem.upload(scale)
+    for i in range(flat.shape[0]):
+        r.lib.call("al_scale_rows", r.mem.ptr(dev) + 4 * i * cols, cols, r.mem.ptr(s_dev) + 4 * i, r.mem.stream())
+    out = r.mem.download(dev)[: flat.size].reshape(arr.shape)
+    return out.astype(arr.dtype) if np.issubdtype(arr.dtype, np.floating) else out.astype(np.float64)
+
+
+# ----------------------------------------------------------------------------- event rendering
+def _clip_of(event, ignore_cache: bool) -> np.ndarray:
+    audio = event.load_audio(ignore_cache=ignore_cache, normalize=True)
+    valid_audio(audio)
+    return np.ascontiguousarray(audio, dtype=np.float32)
+
+
+def _spec_of(event, clip: np.ndarray, n_emitters: int, emitter0: int, ref_db: float) -> planning.EventSpec:
+    if n_emitters == 1 and event.is_moving:
+        raise ValueError("Moving Event has only one emitter!")
+    if n_emitters > 1 and not event.is_moving:
+        raise ValueError("Expected a moving event!")
+    if n_emitters == 0:
+        logger.warning(f"No IRs were found for Event with alias {event.alias}. Audio is being tiled along the "
+                       f"channel dimension to match the expected shape.")
+    return planning.EventSpec(n_samples=len(clip), n_emitters=n_emitters, snr=float(event.snr), emitter0=emitter0,
+                              is_moving=bool(event.is_moving), duration=getattr(event, "duration", None),
+                              ref_db=float(ref_db))
+
+
+def _publish(event, mic_alias: str, res: engine.RenderResult, index: int) -> None:
+    """event.spatial_audio[mic] = scaled (C, La) render, kept in HBM until read (synthesize.py:606)."""
+    event.spatial_audio = as_lazy(getattr(event, "spatial_audio", None))
+    n_ch, n_samp = res.plan.n_capsules, int(res.plan.events["len"][index])
+
+    def fetch():
+        out = res.spatial_audio(index)
+        validate_shape(out.shape, (n_ch, n_samp))
+        return out
+
+    LazyAudioDict.__setitem__(event.spatial_audio, mic_alias, fetch)
+    if not hasattr(event, "_al_device"):
+        event._al_device = {}
+    event._al_device[mic_alias] = (res, index)
+
+
+def compute_dry_audio(event, irs: np.ndarray, event_scale: float, mic_alias: str) -> None:
+    """Direct-path ("dry") render on the reference capsule (reference synthesize.py:432-504).
+
+    ``irs`` are the NORMALISED IRs (C, N, L); the windowed IR of ``ref_ir_channel`` is convolved
+    with the clip on the GPU and scaled by ``event_scale``.
+    """
+    ref, window = getattr(event, "ref_ir_channel", None), getattr(event, "direct_path_time_ms", None)
+    if ref is None and window is None:
+        return
+    if ref is None or window is None:
+        logger.warning("Only one of `ref_ir_channel` or `direct_path_time` were specified when creating the Event. "
+                       "Dry audio will not be computed for this Event. Pass both variables to compute dry audio.")
+        return
+    if ref > irs.shape[0]:
+        raise ValueError(f"Reference channel index out of range for IRs with {irs.shape[0]} channels")
+    lo = int(window[0] * event.sample_rate / 1000)
+    hi = int(window[1] * event.sample_rate / 1000)
+    ir = np.array(irs[ref, 0, :], dtype=np.float64)
+    peak = int(np.argmax(ir))
+    if peak + hi < ir.shape[0]:
+        ir[peak + hi:] = 0
+    if peak - lo > 0:
+        ir[: peak - lo] = 0
+    dry = time_invariant_convolution(np.asarray(event.load_audio(ignore_cache=False)), ir[:, None])[0]
+    if not hasattr(event, "_spatial_audio_dry") or event._spatial_audio_dry is None:
+        event._spatial_audio_dry = {}
+    event._spatial_audio_dry[mic_alias] = dry * event_scale
+
+
+def _dry_from_result(event, irs: np.ndarray, res: engine.RenderResult, index: int, emitter0: int, mic_alias: str):
+    if getattr(event, "ref_ir_channel", None) is None and getattr(event, "direct_path_time_ms", None) is None:
+        return
+    gain = float(res.memory.download(res.emitter_gain)[emitter0]) if irs.shape[1] else 1.0
+    compute_dry_audio(event, np.asarray(irs[:, :1, :], dtype=np.float64) * gain, float(res.stats()[index, 3]), mic_alias)
+
+
+def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEFAULT_REF_DB,
+                       ignore_cache: Optional[bool] = True, fft_size=config.FFT_SIZE, win_size=config.WIN_SIZE,
+                       hop_size=config.HOP_SIZE) -> None:
+    """Render one Event at one microphone (reference synthesize.py:507-608).
+
+    IR energy normalisation, static / tiled / time-variant convolution, truncation to the clip
+    length, SNR + noise-floor scaling and the finite check all run on the GPU; the result is
+    stored in ``event.spatial_audio[mic_alias]`` (and the dry render when the event asks for it).
+    """
+    if mic_alias in getattr(event, "spatial_audio", {}).keys() and not ignore_cache:
+        return
+    n_ch, n_emitters, n_ir = irs.shape
+    clip = _clip_of(event, bool(ignore_cache))
+    spec = _spec_of(event, clip, n_emitters, 0, ref_db)
+    pl = planning.plan_batch([spec], n_ch, max(n_ir, 1), event.sample_rate, hop=int(hop_size), win=int(win_size),
+                             fft_size=int(fft_size))
+    res = get_renderer().render(pl, [clip], irs)
+    res.check_finite()
+    _publish(event, mic_alias, res, 0)
+    _dry_from_result(event, irs, res, 0, 0, mic_alias)
+
+
+def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = False) -> None:
+    """Render every Event of a Scene at every microphone (reference synthesize.py:613-677).
+
+    One batched launch sequence per microphone: all events of the scene are convolved together.
+    """
+    if ignore_cache:
+        scene.state.simulate()
+    else:
+        try:
+            _ = scene.state.irs
+        except AttributeError:
+            scene.state.simulate()
+    validate_scene(scene)
+    irs = scene.state.get_irs()
+    start = time()
+    r = get_renderer()
+    for mic_alias, mic_ir in irs.items():
+        specs, clips, todo = [], [], []
+        counter = 0
+        for event in scene.events.values():
+            n_emit = len(event)
+            cached = mic_alias in getattr(event, "spatial_audio", {}).keys() and not ignore_cache
+            if not cached:
+                clip = _clip_of(event, bool(ignore_cache))
+                specs.append(_spec_of(event, clip, n_emit, counter, scene.ref_db))
+                clips.append(clip)
+                todo.append((event, counter))
+            counter += n_emit
+        if not specs:
+            continue
+        pl = planning.plan_batch(specs, mic_ir.shape[0], mic_ir.shape[2], scene.sample_rate)
+        res = r.render(pl, clips, mic_ir)
+        res.check_finite()
+        for i, (event, em0) in enumerate(todo):
+            _publish(event, mic_alias, res, i)
+            _dry_from_result(event, mic_ir[:, em0: em0 + len(event), :], res, i, em0, mic_alias)
+    logger.info(f"Rendered scene audio in {(time() - start):.2f} seconds!")
+
+
+# ----------------------------------------------------------------------------- mixdown
+def _device_source(r: engine.Renderer, event, mic_alias: str):
+    """(device buffer, offset, len, rows, scale buffer, scale index) of an event's render; uploads host
+    arrays that did not come from this package (scale 1)."""
+    held = getattr(event, "_al_device", {}).get(mic_alias)
+    if held is not None and isinstance(event.spatial_audio, LazyAudioDict):
+        res, idx = held
+        ev = res.plan.events[idx]
+        return res.spatial, int(ev["out_off"]), int(ev["len"]), res.plan.n_capsules, res.event_scale, idx
+    arr = np.ascontiguousarray(event.spatial_audio[mic_alias], dtype=np.float32)
+    return r.mem.upload(arr.reshape(-1)), 0, arr.shape[1], arr.shape[0], r.mem.upload(np.ones(1, np.float32)), 0
+
+
+def generate_scene_audio_from_events(scene) -> None:
+    """Ambience + additive mixdown of all events into ``scene.audio[mic]`` (reference synthesize.py:314-401).
+
+    The mixdown is a tiled segmented sum on the GPU (deterministic, insertion order, float32 like the
+    reference buffer).  ``event._spatial_audio_padded[mic]`` is produced lazily on access instead of
+    allocating E full-scene buffers.
+    """
+    from .ambience import Ambience
+
+    r = get_renderer()
+    for mic_alias in scene.state.microphones.keys():
+        events = list(scene.events.values())
+        srcs = [_device_source(r, ev, mic_alias) for ev in events]
+        channels = max(s[3] for s in srcs)
+        duration = round(scene.duration * scene.sample_rate)
+        amb_dev = []
+        for ambience in scene.ambience.values() if len(scene.ambience) > 0 else []:
+            if not isinstance(ambience, Ambience) and not hasattr(ambience, "load_ambience"):
+                raise TypeError(f"Expected scene ambient noise to be of type Ambience, but got {type(ambience)}!")
+            amb_dev.append(_ambience_on_device(r, ambience, (channels, duration)))
+        # one mixdown launch per distinct source buffer (normally exactly one: the batch render)
+        groups: Dict[int, List[int]] = {}
+        for i, s in enumerate(srcs):
+            groups.setdefault(id(s[0]), []).append(i)
+        scene_dev = None
+        first = True
+        for idxs in groups.values():
+            sub = [srcs[i] for i in idxs]
+            mix = planning.plan_mixdown([events[i].scene_start for i in idxs], [events[i].scene_end for i in idxs],
+                                        [s[2] for s in sub], [s[3] for s in sub], [s[1] for s in sub],
+                                        [s[5] for s in sub], scene.duration, scene.sample_rate, channels)
+            for k in mix.skipped:
+                a, b = planning.event_slot(events[idxs[k]].scene_start, events[idxs[k]].scene_end, scene.sample_rate, duration)
+                logger.warning(f"Skipping event due to invalid slice: start={a}, end={b}")
+            fake = engine.RenderResult(plan=None, memory=r.mem, lib=r.lib, spatial=sub[0][0], event_scale=sub[0][4],
+                                       event_stats=None, emitter_gain=None)
+            pm = r.prepare_mixdown(mix, fake, amb_dev if first else [], scene=scene_dev)
+            scene_dev = pm.run()
+            first = False
+            _attach_padded(events, idxs, mix, mic_alias, channels, duration)
+        host = r.mem.download(scene_dev)[: channels * duration].reshape(channels, duration)
+        valid_audio(host)
+        validate_shape(host.shape, (channels, duration))
+        scene.audio[mic_alias] = host
+
+
+def _ambience_on_device(r: engine.Renderer, ambience, shape):
+    """(device noise, device scalar): load_ambience(normalize=True) x db_to_multiplier(ref_db, mean|noise|)."""
+    dev = ambience.load_ambience_device(r) if hasattr(ambience, "load_ambience_device") else None
+    if dev is None:
+        host = np.ascontiguousarray(ambience.load_ambience(normalize=True), dtype=np.float32)
+        if host.shape != tuple(shape):
+            raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {host.shape}.")
+        dev = r.mem.upload(host.reshape(-1))
+    elif tuple(ambience.device_shape) != tuple(shape):
+        raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {tuple(ambience.device_shape)}.")
+    n = shape[0] * shape[1]
+    stats = r.mem.download(r.row_stats(dev, 1, n)).reshape(-1, 4)
+    mult = db_to_multiplier(ambience.ref_db, stats[0, 0] / n)
+    return dev, r.mem.upload(np.array([mult], dtype=np.float32))
+
+
+def _attach_padded(events, idxs, mix, mic_alias, channels, duration) -> None:
+    """event._spatial_audio_padded[mic] (synthesize.py:381-383) and the dry padded copy (386-395), lazily."""
+    for k, i in enumerate(idxs):
+        ev = events[i]
+        if k in mix.skipped:
+            continue
+        a, b = planning.event_slot(ev.scene_start, ev.scene_end, _sr_of(ev), duration)
+        ev._spatial_audio_padded = as_lazy(getattr(ev, "_spatial_audio_padded", None))
+
+        def fetch(ev=ev, a=a, b=b):
+            full = np.zeros((channels, duration), dtype=np.float32)
+            piece = pad_or_truncate_audio(ev.spatial_audio[mic_alias], b - a)
+            full[: piece.shape[0], a:b] += piece
+            return full
+
+        LazyAudioDict.__setitem__(ev._spatial_audio_padded, mic_alias, fetch)
+        dry = getattr(ev, "_spatial_audio_dry", None) or {}
+        if dry.get(mic_alias) is not None:
+            if getattr(ev, "_spatial_audio_dry_padded", None) is None:
+                ev._spatial_audio_dry_padded = {}
+            line = np.zeros(duration, dtype=np.float32)
+            line[a:b] += pad_or_truncate_audio(dry[mic_alias][None, :], b - a)[0]
+            ev._spatial_audio_dry_padded[mic_alias] = line
+
+
+def _sr_of(ev):
+    return getattr(ev, "sample_rate", config.SAMPLE_RATE)
+
+
+# ----------------------------------------------------------------------------- validation
+def validate_scene(scene) -> None:
+    """Pre-synthesis checks with the reference's messages (reference synthesize.py:681-739)."""
+    if scene.state.num_emitters == 0:
+        raise ValueError("WorldState has no emitters!")
+    if len(scene.state.microphones) == 0:
+        raise ValueError("WorldState has no microphones!")
+    if len(scene.events) == 0:
+        raise ValueError("Scene has no events!")
+    total = 0
+    for alias, ev in scene.events.items():
+        try:
+            total += len(ev)
+        except ValueError:
+            raise ValueError(f"Event with alias '{alias}' has no emitters registered. Has it been orphaned?")
+    if not str(scene.state.name).upper() == "RLR":
+        return
+    ctx = scene.state.ctx
+    if ctx.get_listener_count() == 0:
+        raise ValueError("Ray-tracing engine has no listeners!")
+    if ctx.get_source_count() == 0:
+        raise ValueError("Ray-tracing engine has no sources!")
+    counts = (total, scene.state.num_emitters, ctx.get_source_count())
+    if not all(v == counts[0] for v in counts):
+        raise ValueError(f"Mismatching number of emitters, events, and sources! Got {len(scene.events)} events, "
+                         f"{scene.state.num_emitters} emitters, {ctx.get_source_count()} sources. Have any been orphaned?")
+    capsules = sum(m.n_listeners for m in scene.state.microphones.values())
+    if capsules != ctx.get_listener_count():
+        raise ValueError(f"Mismatching number of microphones and listeners! Got {capsules} capsules, "
+                         f"{ctx.get_listener_count()} listeners. Have any been orphaned?")

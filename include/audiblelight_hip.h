@@ -29,6 +29,10 @@ extern "C" {
 #define AL_E_HIP (-2)
 #define AL_E_UNSUPPORTED (-3)
 
+/* al_batch.flags */
+#define AL_FLAG_NO_IR_NORM 1 /* IRs are already normalised: emitter_gain := 1 (time_invariant_convolution,
+                                 time_variant_convolution called directly, synthesize.py:71,277) */
+
 #define AL_MIN_LOG2_BLOCK 10
 #define AL_MAX_LOG2_BLOCK 14
 
@@ -90,7 +94,7 @@ typedef struct {
   int32_t emitter0;
   int32_t xspec_block0;
   int32_t yspec_block0;
-  int32_t reserved0;
+  int32_t flags;        /* AL_FLAG_* */
 
   const float *twiddle;   /* al_twiddle_init output, B complex */
   const float *audio;     /* mono clips, float32 */
@@ -154,9 +158,50 @@ int al_mixdown(const al_mix *m, al_stream_t stream);
 int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream);
 /* y += a * x over n floats; a = *a_dev (ambience add, synthesize.py:350-356). */
 int al_axpy(float *y, const float *x, const float *a_dev, int64_t n, al_stream_t stream);
-/* Row statistics of a (rows, cols) float32 matrix: out[r] = {sum|x|, max|x|, non-finite count, 0} (doubles). */
+/* Row statistics of a (rows, cols) float32 matrix: out[r] = {sum|x|, max|x|, non-finite count, sum x^2} (doubles). */
 int al_row_stats(const float *x, int32_t rows, int64_t cols, float *partials, double *out, al_stream_t stream);
 int64_t al_row_stats_partials(int32_t rows, int64_t cols); /* floats needed in `partials` */
+
+/* ---- Sample-wise clip operations (A13 peak normalisation, A14 stateless FX; audiblelight/augmentation.py).
+ * All work on float32 device buffers of n samples; ops marked (o) are out-of-place (dst != src).
+ * `params` / `iparams` are HOST pointers (scalars copied into the kernel arguments). */
+#define AL_FX_GAIN 1      /* x *= p[0]                      Gain (augmentation.py:1105-1136), p[0] = 10^(gain_db/20) */
+#define AL_FX_INVERT 2    /* x = -x                         Invert (1557-1580) */
+#define AL_FX_REVERSE 3   /* (o) dst[t] = src[n-1-t]        Reverse (1583-1601) */
+#define AL_FX_FADE 4      /* x *= fade_in(t) * fade_out(t)  Fade (1403-1554): ip = {n_in, n_out, shape_in, shape_out} */
+#define AL_FX_CLIP 5      /* clamp(x, -p[0], p[0])          Clipping (832-868), p[0] = 10^(threshold_db/20) */
+#define AL_FX_TANH 6      /* tanh(p[0] * x)                 Distortion (927-960), p[0] = 10^(drive_db/20) */
+#define AL_FX_BITCRUSH 7  /* rint(x * p[0]) / p[0]          Bitcrush (266-300), p[0] = 2^bit_depth */
+#define AL_FX_PREEMPH 8   /* (o) y[n] = x[n] - c x[n-1], y[0] = x[0] + (2x[0] - x[1])   Preemphasis (1350-1385) */
+#define AL_FX_DEEMPH 9    /* (o) inverse of PREEMPH (IIR + extrapolation correction)    Deemphasis (1388-1400) */
+#define AL_FADE_LINEAR 0
+#define AL_FADE_EXPONENTIAL 1
+#define AL_FADE_LOGARITHMIC 2
+#define AL_FADE_QUARTER_SINE 3
+#define AL_FADE_HALF_SINE 4
+#define AL_FADE_NONE 5
+int al_fx_apply(int op, const float *src, float *dst, int64_t n, const float *params, const int32_t *iparams,
+                al_stream_t stream);
+/* TimeWarp* (augmentation.py:1604-1790): dst[t] for t < n is taken from the concatenation of `n_rows` rows of
+ * `row_len` samples, row q = {src row r = rows[2q], mode = rows[2q+1]: 0 copy, 1 zeros, 2 reversed}, where src row r
+ * is src[r + frame_len * j], j < row_len (the reference iterates librosa.util.frame's (frame_len, n_frames) matrix
+ * by rows); the concatenation is wrap-extended to n samples (Augmentation.process, augmentation.py:117-123). */
+int al_fx_frame_shuffle(const float *src, float *dst, int64_t n, int32_t frame_len, int32_t row_len,
+                        const int32_t *rows, int32_t n_rows, al_stream_t stream);
+/* ---- Ambience (A12): Timmer-Koenig (1/f)^beta noise, audiblelight/ambience.py:271-375.
+ * The host draws the two standard-normal sets with numpy's default_rng(seed) (PCG64 + ziggurat, ambience.py:351-356:
+ * the reference's RNG stream is data-dependent and is not re-implemented on the device); everything after the draws
+ * runs here: spectral shaping, DC/Nyquist fix-up, an inverse real FFT of ARBITRARY length n, the 1/sigma scale. */
+/* floats of workspace al_noise_irfft needs for `rows` series of length n */
+int64_t al_noise_workspace_floats(int32_t rows, int64_t n);
+/* out[r, :] = irfft((zr + i zi) * shape)[r] / sigma ; zr, zi: (rows, n/2+1) float32 draws; shape: n/2+1 float32. */
+int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t rows, int64_t n, float inv_sigma,
+                   float *out, float *workspace, al_stream_t stream);
+/* x[r, :] *= scale[r]: per-channel peak normalisation (ambience.py:211-214) after al_row_stats. */
+int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream);
+
+/* dst[t] = src[t mod m] for t < n: np.pad(..., mode="wrap") of Augmentation.process. */
+int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -432,3 +432,57 @@ def fade_envelope(n: int, sr: int, in_len: float, out_len: float, in_shape: str,
 
 def fx_fade(a, sr, in_len, out_len, in_shape, out_shape):
     return a * fade_envelope(a.shape[-1], sr, in_len, out_len, in_shape, out_shape)
+
+
+def fx_clipping(a, threshold_db):  # pedalboard.Clipping: hard clip at +-10^(dB/20) (augmentation.py:832-868)
+    thr = np.float32(10.0 ** (threshold_db / 20.0))
+    return np.clip(a, -thr, thr)
+
+
+def fx_distortion(a, drive_db):  # pedalboard.Distortion: tanh waveshaper after a drive gain (augmentation.py:927-960)
+    return np.tanh(np.float32(10.0 ** (drive_db / 20.0)) * a)
+
+
+def fx_bitcrush(a, bit_depth):  # pedalboard.Bitcrush: round to 2^bits levels (augmentation.py:266-300)
+    q = np.float32(2.0 ** bit_depth)
+    return np.rint(a * q) / q
+
+
+def fx_preemphasis(a, coef):
+    """librosa.effects.preemphasis (0.11): lfilter([1,-coef],[1]) with zi = 2*y[0]-y[1] (augmentation.py:1385)."""
+    a = np.asarray(a, dtype=np.float64)
+    out, _ = sp_signal.lfilter([1.0, -coef], [1.0], a, zi=np.atleast_1d(2 * a[0] - a[1]))
+    return out
+
+
+def fx_deemphasis(a, coef):
+    """librosa.effects.deemphasis (0.11): inverse filter from zero state minus the extrapolation term."""
+    a = np.asarray(a, dtype=np.float64)
+    out, _ = sp_signal.lfilter([1.0], [1.0, -coef], a, zi=np.zeros(1))
+    return out - ((2 - coef) * a[0] - a[1]) / (3 - coef) * coef ** np.arange(len(a))
+
+
+def fx_timewarp(a, sr, fps, decisions, mode):
+    """TimeWarp* (augmentation.py:1604-1790).  ``decisions`` = the random()<prob outcomes per iterated row.
+
+    The reference frames with librosa.util.frame (shape (frame_len, n_frames)) and iterates it by rows.
+    """
+    fl = round(sr / fps)
+    n = len(a)
+    if fl > n:
+        sliced = a[None, :]
+    else:
+        nf = 1 + (n - fl) // fl
+        sliced = np.stack([a[j * fl: j * fl + fl] for j in range(nf)], axis=-1)  # (fl, nf)
+    rows = []
+    for row, hit in zip(sliced, decisions):
+        if mode == "silence":
+            rows.append(np.zeros(len(row)) if hit else row)
+        elif mode == "duplicate":
+            rows.extend([row, row] if hit else [row])
+        elif mode == "remove":
+            if not hit:
+                rows.append(row)
+        elif mode == "reverse":
+            rows.append(row[::-1] if hit else row)
+    return np.concatenate(rows) if rows else a

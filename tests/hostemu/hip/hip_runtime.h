@@ -55,24 +55,26 @@ void launch(dim3 grid, dim3 block, F &&body) {
   ctx.wave_bar.resize(nw);
   for (unsigned w = 0; w < nw; ++w) pthread_barrier_init(&ctx.wave_bar[w], nullptr, std::min(64u, nt - 64 * w));
   ctx.xbuf.assign(nt, 0.0);
-  for (unsigned bz = 0; bz < grid.z; ++bz)
-    for (unsigned by = 0; by < grid.y; ++by)
-      for (unsigned bx = 0; bx < grid.x; ++bx) {
-        std::vector<std::thread> th;
-        th.reserve(nt);
-        for (unsigned t = 0; t < nt; ++t)
-          th.emplace_back([&, t] {
-            t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+  // one host thread per HIP thread for the whole launch; workgroups run one after another (a barrier
+  // separates them because `__shared__` is a single static image).  Kernels here only return early
+  // for a whole workgroup, so every thread reaches the end-of-workgroup barrier.
+  std::vector<std::thread> th;
+  th.reserve(nt);
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] {
+      t_threadIdx = dim3(t % block.x, (t / block.x) % block.y, t / (block.x * block.y));
+      t_blockDim = block;
+      t_gridDim = grid;
+      t_ctx = &ctx;
+      for (unsigned bz = 0; bz < grid.z; ++bz)
+        for (unsigned by = 0; by < grid.y; ++by)
+          for (unsigned bx = 0; bx < grid.x; ++bx) {
             t_blockIdx = dim3(bx, by, bz);
-            t_blockDim = block;
-            t_gridDim = grid;
-            t_ctx = &ctx;
             body();
-            // a thread that returns early must still let the others pass later barriers: kernels in
-            // this code base only return early for the whole workgroup, so nothing to do here.
-          });
-        for (auto &x : th) x.join();
-      }
+            if (nt > 1) pthread_barrier_wait(&ctx.block_bar);
+          }
+    });
+  for (auto &x : th) x.join();
   pthread_barrier_destroy(&ctx.block_bar);
   for (auto &b : ctx.wave_bar) pthread_barrier_destroy(&b);
 }

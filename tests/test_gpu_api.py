@@ -1,0 +1,46 @@
+"""The reference-named API on the real MI355X: the same scenarios as tests/test_hostemu_api.py, run
+through the gfx950 library (audiblelight_amd/csrc/libaudiblelight_hip.so) instead of the host emulation."""
+import pytest
+
+from tests import test_hostemu_api as scenarios
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def gpu_renderer():
+    from audiblelight_amd import engine, synthesize as syn
+
+    r = engine.Renderer()
+    assert r.lib.path.endswith("libaudiblelight_hip.so")
+    syn.set_renderer(r)
+    yield r
+    syn.set_renderer(None)
+
+
+test_scene_generate_matches_reference = scenarios.test_scene_generate_matches_reference
+test_render_cache_and_host_arrays = scenarios.test_render_cache_and_host_arrays
+test_render_event_audio_and_errors = scenarios.test_render_event_audio_and_errors
+test_validate_scene_messages = scenarios.test_validate_scene_messages
+test_standalone_convolutions = scenarios.test_standalone_convolutions
+test_pointwise_fx_match_definitions = scenarios.test_pointwise_fx_match_definitions
+test_timewarp_matches_reference_semantics = scenarios.test_timewarp_matches_reference_semantics
+test_event_fx_chain_and_dict_roundtrip = scenarios.test_event_fx_chain_and_dict_roundtrip
+test_powerlaw_noise_matches_reference = scenarios.test_powerlaw_noise_matches_reference
+test_powerlaw_misc_and_ambience_class = scenarios.test_powerlaw_misc_and_ambience_class
+test_scene_with_device_ambience = scenarios.test_scene_with_device_ambience
+
+
+def test_large_noise_lengths_statistics():
+    """Full-size ambience (60 s @ 48 kHz = 2,880,000 samples, smooth length) and an awkward prime-ish
+    length through Bluestein: unit variance and the requested spectral slope (reference tests/test_ambience.py:30-58)."""
+    import numpy as np
+
+    from audiblelight_amd import ambience as amb
+    from oracle import synth_oracle as orc
+
+    x = amb.powerlaw_psd_gaussian(0, (2, 2_880_000), seed=1)
+    assert abs(x.std() - 1.0) < 0.01 and abs(x.mean()) < 0.01
+    small = amb.powerlaw_psd_gaussian(1, (2, 100_003), seed=3)      # 100003 is prime -> Bluestein
+    ref = orc.powerlaw_noise(1, (2, 100_003), seed=3)
+    assert np.sqrt(np.mean((small - ref) ** 2)) / ref.std() < 1e-5

@@ -1,0 +1,226 @@
+"""The reference-named Python API (audiblelight_amd.synthesize / augmentation / core) driven through the
+host-emulated kernels: covers the host logic (caching, lazy dicts, errors, mixdown planning) on CPU.
+The same scenarios run on the real GPU in tests/test_gpu_api.py."""
+import random
+
+import numpy as np
+import pytest
+
+from audiblelight_amd import _hip, augmentation as aug, core, engine, synthesize as syn
+from oracle import synth_oracle as orc
+from tests import hostemu
+from tests.conftest import rel_rms
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emu_renderer():
+    r = engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
+    syn.set_renderer(r)
+    yield r
+    syn.set_renderer(None)
+
+
+def build_g8_scene(golden, with_ambience=True):
+    sr = 8000
+    irs, events = [], []
+    for i, (na, ne, st, snr, mv, dry) in enumerate(golden["g8_specs"]):
+        irs.append(golden[f"g8_irs{i}"])
+        events.append(core.Event(f"ev{i}", golden[f"g8_audio{i}"], sr, snr=float(snr), scene_start=float(st),
+                                 n_emitters=int(ne), ref_ir_channel=1 if dry else None,
+                                 direct_path_time_ms=[2, 20] if dry else None))
+    scene = core.Scene(2.0, core.StaticIRState({"mic000": np.concatenate(irs, axis=1)}), sample_rate=sr, ref_db=-65)
+    for ev in events:
+        scene.add_event(ev)
+    if with_ambience:
+        class GoldenAmbience:
+            alias, ref_db = "a0", -65
+
+            def load_ambience(self, ignore_cache=False, normalize=True):
+                return golden["g8_ambience"]
+        scene.add_ambience(GoldenAmbience())
+    return scene
+
+
+def test_scene_generate_matches_reference(golden):
+    scene = build_g8_scene(golden)
+    out = scene.generate()
+    assert out["mic000"].dtype == np.float32 and out["mic000"].shape == golden["g8_scene"].shape
+    assert rel_rms(out["mic000"], golden["g8_scene"]) < TOL
+    for i, ev in enumerate(scene.events.values()):
+        assert ev.spatial_audio.is_resident("mic000")           # still in "HBM" until somebody reads it
+        got = ev.spatial_audio["mic000"]
+        assert isinstance(got, np.ndarray) and not ev.spatial_audio.is_resident("mic000")
+        assert rel_rms(got, golden[f"g8_spatial{i}"]) < TOL
+        assert rel_rms(ev._spatial_audio_padded["mic000"], golden[f"g8_padded{i}"]) < TOL
+    ev4 = scene.events["ev4"]
+    assert rel_rms(ev4._spatial_audio_dry["mic000"], golden["g8_dry4"]) < TOL
+    assert rel_rms(ev4._spatial_audio_dry_padded["mic000"], golden["g8_dry_padded4"]) < TOL
+
+
+def test_render_cache_and_host_arrays(golden):
+    scene = build_g8_scene(golden, with_ambience=False)
+    syn.render_audio_for_all_scene_events(scene)
+    first = scene.events["ev0"]._al_device["mic000"][0]
+    syn.render_audio_for_all_scene_events(scene)                 # cached: nothing re-rendered (synthesize.py:541-542)
+    assert scene.events["ev0"]._al_device["mic000"][0] is first
+    syn.render_audio_for_all_scene_events(scene, ignore_cache=True)
+    assert scene.events["ev0"]._al_device["mic000"][0] is not first
+    # events rendered elsewhere (plain ndarrays in spatial_audio) are mixed as well
+    for ev in scene.events.values():
+        host = ev.spatial_audio["mic000"]
+        ev.spatial_audio = {"mic000": host}
+        ev._al_device = {}
+    syn.generate_scene_audio_from_events(scene)
+    want = golden["g8_scene"].astype(np.float64) - orc.db_gain(-65, np.mean(np.abs(golden["g8_ambience"]))) * golden["g8_ambience"]
+    assert rel_rms(scene.audio["mic000"], want) < 2e-4
+
+
+def test_render_event_audio_and_errors(golden):
+    a, h = golden["g1_audio"], golden["g1_irs"]
+    ev = core.Event("g1", a, 8000, snr=10.0)
+    syn.render_event_audio(ev, h, "mic000", ref_db=-65)
+    assert rel_rms(ev.spatial_audio["mic000"], golden["g1_spatial"]) < TOL
+    with pytest.raises(ValueError, match="Moving Event has only one emitter!"):
+        syn.render_event_audio(core.Event("m", a, 8000, n_emitters=1, is_moving=True), h, "mic000")
+    with pytest.raises(ValueError, match="Expected a moving event!"):
+        syn.render_event_audio(core.Event("s", a, 8000, n_emitters=3, is_moving=False), np.repeat(h, 3, 1), "mic000")
+    # reference tests/test_synthesize.py:25-39
+    with pytest.raises(ValueError, match="Only mono input is supported"):
+        syn.time_invariant_convolution(np.ones((5, 2)), np.ones((5, 4)))
+    with pytest.raises(ValueError, match="Expected shape of IR should be"):
+        syn.time_invariant_convolution(np.ones(5), np.ones(5))
+    bad = core.Event("nan", np.array([0.0, np.nan, 1.0], dtype=np.float32), 8000)
+    with pytest.raises(ValueError, match="not finite"):
+        syn.render_event_audio(bad, h, "mic000")
+
+
+def test_validate_scene_messages(golden):
+    scene = build_g8_scene(golden, with_ambience=False)
+    syn.validate_scene(scene)
+    empty = core.Scene(1.0, core.StaticIRState({"mic000": np.zeros((4, 2, 10))}))
+    with pytest.raises(ValueError, match="Scene has no events!"):
+        syn.validate_scene(empty)
+    with pytest.raises(ValueError, match="WorldState has no emitters!"):
+        syn.validate_scene(core.Scene(1.0, core.StaticIRState({"mic000": np.zeros((4, 0, 10))})))
+
+
+def test_standalone_convolutions(golden):
+    a, h = golden["g1_audio"], golden["g1_irs"].astype(np.float64)
+    full = syn.time_invariant_convolution(a, h[:, 0].T)
+    assert full.shape == golden["g1_full_conv"].shape and rel_rms(full, golden["g1_full_conv"]) < TOL
+    a3, h3 = golden["g3a_audio"], golden["g3a_irs"].astype(np.float64)
+    hn = orc.unit_energy_irs(h3.transpose(1, 0, 2)).transpose(1, 0, 2)
+    ev = core.Event("mv", a3, 8000, n_emitters=3)
+    raw = syn.time_variant_convolution(hn, ev)
+    assert raw.shape == golden["g3a_raw"].shape and rel_rms(raw, golden["g3a_raw"]) < TOL
+    got = syn.normalize_irs(golden["g5_irs"].transpose(1, 0, 2)).transpose(1, 0, 2)
+    assert rel_rms(got, golden["g5_norm"]) < 1e-6
+    # scalar known answers (reference tests/test_synthesize.py:42-57,307-337)
+    assert np.max(np.abs(syn.apply_snr(np.array([0.0, 0.5, -0.5, 1.0, -1.0]), 2.0))) == pytest.approx(2.0)
+    assert syn.db_to_multiplier(20.0, 0.1) == pytest.approx(100.0, abs=1e-4)
+
+
+@pytest.mark.parametrize("n", [8000, 4001])
+def test_pointwise_fx_match_definitions(n):
+    rng = np.random.default_rng(n)
+    x = (0.8 * rng.standard_normal(n)).astype(np.float32)
+    sr = 8000
+    np.testing.assert_allclose(aug.Gain(sr, gain_db=-4.5)(x), orc.fx_gain(x, -4.5), rtol=1e-6)
+    np.testing.assert_array_equal(aug.Invert(sr)(x), -x)
+    np.testing.assert_array_equal(aug.Reverse(sr)(x), x[::-1])
+    np.testing.assert_allclose(aug.Clipping(sr, threshold_db=-6)(x), orc.fx_clipping(x, -6), rtol=1e-6)
+    np.testing.assert_allclose(aug.Distortion(sr, drive_db=12.0)(x), orc.fx_distortion(x, 12.0), atol=2e-6)
+    np.testing.assert_allclose(aug.Bitcrush(sr, bit_depth=8)(x), orc.fx_bitcrush(x, 8), atol=1e-7)
+    assert rel_rms(aug.Preemphasis(sr, coef=0.97)(x), orc.fx_preemphasis(x, 0.97)) < 1e-6
+    assert rel_rms(aug.Deemphasis(sr, coef=0.9)(x), orc.fx_deemphasis(x, 0.9)) < 1e-5
+    # the two emphasis filters invert each other (librosa's design)
+    assert rel_rms(aug.Deemphasis(sr, coef=0.5)(aug.Preemphasis(sr, coef=0.5)(x)), x) < 1e-5
+    for shape in aug.Fade.FADE_SHAPES:
+        f = aug.Fade(sr, fade_in_len=0.3, fade_out_len=0.2, fade_in_shape=shape, fade_out_shape=shape)
+        assert rel_rms(f(x), orc.fx_fade(x.astype(np.float64), sr, 0.3, 0.2, shape, shape)) < 1e-5
+    # reference tests/test_augmentation.py:300-327 and 504-515
+    y = aug.Fade(sr, 0.25, 0.25, "linear", "linear")(np.ones(n, dtype=np.float32))
+    assert abs(y[0]) < 1e-6 and abs(y[-1]) < 1e-6
+    np.testing.assert_array_equal(aug.Invert(sr)(np.ones(16, dtype=np.float32)), -np.ones(16))
+    assert rel_rms(aug.peak_normalize(x), orc.peak_normalise_clip(x)) < 1e-6
+
+
+@pytest.mark.parametrize("cls,mode", [(aug.TimeWarpSilence, "silence"), (aug.TimeWarpDuplicate, "duplicate"),
+                                      (aug.TimeWarpRemove, "remove"), (aug.TimeWarpReverse, "reverse")])
+@pytest.mark.parametrize("n,fps", [(8000, 7.0), (3000, 2.0)])
+def test_timewarp_matches_reference_semantics(cls, mode, n, fps):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal(n).astype(np.float32)
+    sr = 8000
+    fx = cls(sr, fps=fps, prob=0.3)
+    random.seed(11)
+    got = fx(x)
+    random.seed(11)
+    fl = round(sr / fps)
+    decisions = [random.random() < 0.3 for _ in range(1 if fl > n else fl)]
+    want = orc.fx_wrap(lambda a: orc.fx_timewarp(a, sr, fps, decisions, mode), x)
+    assert got.shape == x.shape
+    np.testing.assert_allclose(got, want, atol=0)
+
+
+def test_event_fx_chain_and_dict_roundtrip():
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(2000).astype(np.float32)
+    chain = [aug.Gain(8000, gain_db=3.0), aug.Invert(8000)]
+    ev = core.Event("fx", x, 8000, augmentations=chain)
+    want = orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(x, 3.0)))
+    assert rel_rms(ev.load_audio(), want) < 1e-6
+    assert ev.load_audio() is ev.audio                      # cached (event.py:511-512)
+    ev.register_augmentations(aug.Reverse(8000))
+    assert ev.audio is None                                 # registering FX invalidates caches (event.py:739-782)
+    d = chain[0].to_dict()
+    assert d == dict(name="Gain", sample_rate=8000, gain_db=3.0)
+    assert aug.Augmentation.from_dict(d) == chain[0]
+
+
+@pytest.mark.parametrize("beta", [0, 1, 2, -1])
+@pytest.mark.parametrize("n", [1000, 1001])   # 1000: mixed radix 2/5; 1001 = 7*11*13: Bluestein
+def test_powerlaw_noise_matches_reference(golden, beta, n):
+    from audiblelight_amd import ambience as amb
+
+    got = amb.powerlaw_psd_gaussian(beta, (4, n))
+    assert got.shape == (4, n)
+    assert rel_rms(got, golden[f"g6_b{beta}_n{n}"]) < 2e-6
+
+
+def test_powerlaw_misc_and_ambience_class(golden):
+    from audiblelight_amd import ambience as amb
+
+    assert rel_rms(amb.powerlaw_psd_gaussian(1, (2, 512), fmin=0.1, seed=7), golden["g6_fmin"]) < 2e-6
+    assert rel_rms(amb.powerlaw_psd_gaussian(1, 300), golden["g6_1d"]) < 2e-6
+    with pytest.raises(ValueError, match="fmin"):
+        amb.powerlaw_psd_gaussian(1, 16, fmin=0.7)
+    a = amb.Ambience(channels=4, duration=0.5, alias="amb", noise="pink", ref_db=-60, sample_rate=8000)
+    noise = a.load_ambience()
+    assert rel_rms(noise, golden["g7_noise"]) < 2e-6
+    np.testing.assert_allclose(np.abs(noise).max(axis=1), 1.0, rtol=1e-6)   # reference tests/test_ambience.py:134-136
+    assert a.load_ambience() is noise                                       # cached
+    assert amb.Ambience.from_dict(a.to_dict()) == a
+    with pytest.raises(AttributeError):
+        amb.Ambience(channels=1, duration=1, alias="x")
+    with pytest.raises(KeyError):
+        amb.Ambience(channels=1, duration=1, alias="x", noise="mauve")
+    # file-style ambience: a mono clip tiled over channels and time (reference ambience.py:172-208)
+    clip = np.arange(1, 301, dtype=np.float32) / 300
+    t = amb.Ambience(channels=3, duration=0.1, alias="t", clip=clip, sample_rate=8000).load_ambience()
+    np.testing.assert_allclose(t, orc.peak_normalise_rows(orc.tile_ambience(clip, 3, 800).astype(np.float64)), rtol=1e-6)
+
+
+def test_scene_with_device_ambience(golden):
+    from audiblelight_amd import ambience as amb
+
+    scene = build_g8_scene(golden, with_ambience=False)
+    scene.add_ambience(amb.Ambience(channels=4, duration=2.0, alias="a0", noise="white", ref_db=-65, sample_rate=8000))
+    out = scene.generate()["mic000"]
+    assert rel_rms(out, golden["g8_scene"]) < TOL
+    with pytest.raises(ValueError, match="does not match expected shape"):
+        bad = build_g8_scene(golden, with_ambience=False)
+        bad.add_ambience(amb.Ambience(channels=4, duration=1.0, alias="a0", noise="white", sample_rate=8000))
+        bad.generate()

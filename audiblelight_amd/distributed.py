@@ -1,0 +1,98 @@
+"""Multi-GPU batch rendering: independent scenes sharded over one process per GPU.
+
+Scenes never exchange data while rendering (the reference's dataset scripts are a serial loop over
+independent scenes, scripts/generate/benchmark.py:44-77), so the only collective is the optional
+gather of finished ``scene.audio`` buffers to one rank at the end: every peer sends over its own
+xGMI link into the root (RCCL ``gather``; ``backend="nccl"`` is RCCL on ROCm, ``"gloo"`` on CPU tests).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
+    """Static round-robin ownership: item i belongs to rank i % world_size."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    return list(range(rank, n_items, world_size))
+
+
+def init_process_group(backend: Optional[str] = None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    if dist.is_initialized():
+        return dist
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    kwargs = {}
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        kwargs["device_id"] = torch.device(f"cuda:{local}")
+    dist.init_process_group(backend, **kwargs)
+    return dist
+
+
+def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, device=None) -> Optional[Dict[int, np.ndarray]]:
+    """Collect per-scene (C, T) float32 buffers on rank ``dst``.
+
+    ``local`` maps scene index -> torch tensor (device or CPU) or ndarray owned by this rank under
+    ``shard_indices``.  Buffers may differ in shape between scenes: shapes travel first (tiny all_gather),
+    then each round of the round-robin is one ``gather`` of equally padded tensors.
+    """
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = dist.get_backend()
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+
+    def as_tensor(x):
+        t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
+        return t.to(dev, dtype=torch.float32)
+
+    mine = shard_indices(n_items, rank, world)
+    rounds = -(-n_items // world)
+    shapes = torch.zeros((rounds, 2), dtype=torch.int64, device=dev)
+    for r, idx in enumerate(mine):
+        shapes[r, 0], shapes[r, 1] = local[idx].shape[0], local[idx].shape[1]
+    all_shapes = [torch.zeros_like(shapes) for _ in range(world)]
+    dist.all_gather(all_shapes, shapes)
+    out: Dict[int, np.ndarray] = {}
+    for r in range(rounds):
+        sizes = [int(all_shapes[p][r, 0] * all_shapes[p][r, 1]) for p in range(world)]
+        pad = max(max(sizes), 1)
+        send = torch.zeros(pad, dtype=torch.float32, device=dev)
+        if r < len(mine):
+            flat = as_tensor(local[mine[r]]).reshape(-1)
+            send[: flat.numel()] = flat
+        recv = [torch.zeros(pad, dtype=torch.float32, device=dev) for _ in range(world)] if rank == dst else None
+        dist.gather(send, recv, dst=dst)
+        if rank == dst:
+            for p in range(world):
+                idx = r * world + p
+                if idx < n_items:
+                    c, t = int(all_shapes[p][r, 0]), int(all_shapes[p][r, 1])
+                    out[idx] = recv[p][: c * t].reshape(c, t).cpu().numpy()
+    return out if rank == dst else None
+
+
+def render_scenes(n_scenes: int, render_fn: Callable[[int], "object"], gather: bool = True, dst: int = 0):
+    """Render scenes [0, n_scenes) across the process group.
+
+    ``render_fn(i)`` renders scene i on this rank's GPU and returns its (C, T) float32 buffer (device
+    tensor or ndarray).  Returns {index: ndarray} on ``dst`` when ``gather`` else this rank's own results.
+    """
+    import torch.distributed as dist
+
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    local = {i: render_fn(i) for i in shard_indices(n_scenes, rank, world)}
+    if not gather or world == 1:
+        return {i: (v if isinstance(v, np.ndarray) else v.cpu().numpy()) for i, v in local.items()} if world == 1 else local
+    return gather_buffers(local, n_scenes, dst=dst)

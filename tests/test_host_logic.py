@@ -1,0 +1,116 @@
+"""Host-side logic (no GPU, no kernels): planning tables, slot rounding, chunking, C-ABI surface."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from audiblelight_amd import _hip, plan as planning
+from oracle import synth_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_library_exports_every_declared_symbol():
+    """The gfx950 library loads on a machine without a GPU and exports exactly what the header declares."""
+    import __graft_entry__ as entry
+
+    entry.build()
+    lib = _hip.Library(entry.LIB)
+    header = open(os.path.join(ROOT, "include", "audiblelight_hip.h")).read()
+    declared = set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
+    assert lib.call("al_abi_version") == 1
+    assert lib.call("al_twiddle_bytes", 13) == 8 * 8192 and lib.call("al_twiddle_bytes", 9) == -1
+    assert lib.call("al_row_stats_partials", 3, 40000) == 4 * 3 * 3
+    assert lib.call("al_noise_workspace_floats", 2, 1000) > 0
+    # argument validation happens before any launch, so it is checkable without a GPU
+    with pytest.raises(_hip.HipError, match="null batch"):
+        lib.call("al_render_batch", None, None)
+    bad = _hip.AlBatch(log2_block=3, n_capsules=1, hop=128)
+    with pytest.raises(_hip.HipError, match=r"log2_block must be in \[10, 14\]"):
+        lib.call("al_ir_spectra", ct.byref(bad), None)
+
+
+def test_struct_layouts_match_the_header():
+    assert _hip.EVENT_DTYPE.itemsize == 56 and _hip.STREAM_DTYPE.itemsize == 32
+    assert ct.sizeof(_hip.AlBatch) == 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 15 * 8
+    assert ct.sizeof(_hip.AlMix) == 6 * 4 + 11 * 8
+    assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _hip.Library(str(tmp_path / "nope.so"))
+
+
+def test_event_slot_uses_bankers_rounding():
+    # Python round(): 0.5 -> 0, 1.5 -> 2, 2.5 -> 2 (reference synthesize.py:361-362)
+    assert planning.event_slot(0.5, 2.5, 1, 100) == (0, 2)
+    assert planning.event_slot(1.5, 3.5, 1, 100) == (2, 4)
+    assert planning.event_slot(-1.0, 500.0, 1, 100) == (0, 100)
+    assert planning.event_slot(0.5, 2.5, 1, 100) == orc.event_slot(0.5, 2.5, 1, 100)
+
+
+def test_interpolation_matrix_matches_oracle():
+    for n_ir, dur, sr in ((3, 0.75, 8000), (5, 1.125, 8000), (32, 7.75, 48000), (2, 0.1, 44100)):
+        w = planning.generate_interpolation_matrix(np.linspace(0, dur, n_ir), sr, 128)
+        np.testing.assert_array_equal(w, orc.crossfade_weights(np.linspace(0, dur, n_ir), sr, 128))
+        assert planning.stft_frame_count(int(dur * sr)) == orc.frame_count(int(dur * sr))
+
+
+def test_plan_tables_static_and_moving():
+    specs = [planning.EventSpec(5000, 1, 10.0, emitter0=0), planning.EventSpec(4000, 0, 5.0, emitter0=1),
+             planning.EventSpec(9000, 3, 5.0, emitter0=1, is_moving=True, duration=9000 / 8000),
+             planning.EventSpec(1024, 1, 5.0, emitter0=4)]
+    pl = planning.plan_batch(specs, 4, 1500, 8000, log2_block=10)
+    ev, st = pl.events, pl.streams
+    assert list(ev["n_blocks"]) == [5, 4, 9, 1] and pl.n_partitions == 2 and pl.n_emitters == 5
+    assert list(ev["n_streams"]) == [1, 0, 3, 1] and list(ev["stream0"]) == [0, 1, 2, 5]
+    assert list(ev["yspec_base"]) == [0, 20, 20, 56]        # the zero-emitter event owns no spectra
+    assert ev["audio_off"][1] == 5000 and ev["out_off"][1] == 4 * 5000
+    assert st["w_off"][0] == -1 and st["n_j"][0] == 5 and st["gain"][2] == 512.0
+    w, n_frames = orc.tv_frames(9000, 9000 / 8000, 3, 8000)
+    assert ev["valid_len"][2] == min(9000, n_frames * 128 - 256) and st["w_len"][2] == n_frames
+    # every non-zero sample of each envelope lies inside the planned block range of its stream
+    env = orc.crossfade_envelopes(w, n_frames, 9000)
+    for l in range(3):
+        nz = np.flatnonzero(env[l])
+        j_lo, n_j = int(st["j_lo"][2 + l]), int(st["n_j"][2 + l])
+        assert (j_lo - 1) * 1024 <= nz[0] and nz[-1] < (j_lo + n_j) * 1024
+    with pytest.raises(ValueError, match="Moving Event has only one emitter!"):
+        planning.plan_batch([planning.EventSpec(10, 1, 1.0, is_moving=True)], 1, 10, 8000)
+    with pytest.raises(ValueError, match="Expected a moving event!"):
+        planning.plan_batch([planning.EventSpec(10, 2, 1.0)], 1, 10, 8000)
+    with pytest.raises(ValueError, match="win_size == 2"):
+        planning.plan_batch(specs, 4, 1500, 8000, hop=100, win=256)
+
+
+def test_chunks_partition_the_tables():
+    specs = [planning.EventSpec(3000 + 100 * i, 1, 10.0, emitter0=i) for i in range(7)]
+    pl = planning.plan_batch(specs, 3, 2000, 8000, log2_block=10)
+    chunks = pl.chunks(3)
+    assert [c["n_events"] for c in chunks] == [3, 3, 1]
+    assert sum(c["xspec_blocks"] for c in chunks) == pl.xspec_blocks
+    assert sum(c["yspec_blocks"] for c in chunks) == pl.yspec_blocks
+    assert [c["emitter0"] for c in chunks] == [0, 3, 6] and all(c["n_emitters"] == c["n_events"] for c in chunks)
+    assert pl.chunks(None)[0]["n_events"] == 7
+
+
+def test_mix_plan_tiles_and_clipping():
+    # event 2 runs past the scene end, event 1 is empty after rounding, event 3 is longer than its slot
+    mix = planning.plan_mixdown(starts=[0.1, 5.0, 1.9, 0.0], ends=[0.6, 5.5, 2.6, 0.25], lens=[4000, 100, 5600, 9000],
+                                rows=[4, 4, 4, 2], src_offsets=[0, 16000, 16400, 38800], event_index=[0, 1, 2, 3],
+                                duration=2.0, sample_rate=8000, n_capsules=4, tile=4096)
+    assert mix.skipped == [1] and mix.n_samples == 16000 and mix.n_tiles == 4
+    assert list(mix.slot_start) == [800, 15200, 0] and list(mix.slot_count) == [4000, 800, 2000]
+    assert list(mix.slot_event) == [0, 2, 3] and list(mix.slot_rows) == [4, 4, 2]
+    lists = [list(mix.tile_events[mix.tile_ptr[t]: mix.tile_ptr[t + 1]]) for t in range(4)]
+    assert lists == [[0, 2], [0], [], [1]]
+
+
+def test_block_size_choice():
+    assert planning.choose_log2_block(96000, 192000) == 13
+    assert planning.choose_log2_block(1000, 6000) == 10
+    assert planning.choose_log2_block(5000, 3000) == 12

@@ -162,7 +162,7 @@ __device__ __forceinline__ void load_pass_twiddles(PassTwiddles<LOG2M, PASS> &t,
 //   butterfly j = tid + T*b reads in[j + r*M/R]      = v[b + r*NB]
 //   k = j mod NS;  factor exp(DIR*2*pi*i*r*k/(NS*R))
 //   out[(j - k)*R + k + q*NS] = X[q]
-template <int LOG2M, int DIR, int PASS>
+template <int LOG2M, int DIR, int PASS, bool TO_REGS = false>
 __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassTwiddles<LOG2M, PASS> &t, int tid) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   constexpr int R = fft_radix(LOG2M, PASS);
@@ -180,6 +180,33 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassT
     }
     // all LDS reads of this pass are done once every thread is here
     __syncthreads();
+  }
+  if (TO_REGS) {
+    // Final pass (NS * R == M): output q of butterfly b is element tid + T*(b + q*NB), i.e. the thread's
+    // own slot b + q*NB, so the natural-order result can stay in registers: v[m] = X[tid + T*m].
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (R == 16) {
+        bfly16<DIR>(v);
+        float2 o[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) o[q] = v[4 * (q & 3) + (q >> 2)];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = o[q];
+      } else if (R == 8) {
+        float2 x[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) x[r] = v[b + r * NB];
+        bfly8<DIR>(x);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[b + q * NB] = x[q];
+      } else if (R == 4) {
+        bfly4<DIR>(v[b], v[b + NB], v[b + 2 * NB], v[b + 3 * NB]);
+      } else {
+        bfly2<DIR>(v[b], v[b + NB]);
+      }
+    }
+    return;
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -214,7 +241,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassT
   __syncthreads();
 }
 
-template <int LOG2M, int DIR, int PASS>
+template <int LOG2M, int DIR, int PASS, bool LAST_REGS>
 struct FftPasses {
   static __device__ __forceinline__ void run(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid,
                                              const PassTwiddles<LOG2M, PASS> &cur) {
@@ -222,9 +249,9 @@ struct FftPasses {
       PassTwiddles<LOG2M, PASS + 1> nxt;
       load_pass_twiddles<LOG2M, DIR, PASS + 1>(nxt, tw, tid);  // in flight during this pass
       fft_pass<LOG2M, DIR, PASS>(v, s, cur, tid);
-      FftPasses<LOG2M, DIR, PASS + 1>::run(v, s, tw, tid, nxt);
+      FftPasses<LOG2M, DIR, PASS + 1, LAST_REGS>::run(v, s, tw, tid, nxt);
     } else {
-      fft_pass<LOG2M, DIR, PASS>(v, s, cur, tid);
+      fft_pass<LOG2M, DIR, PASS, LAST_REGS>(v, s, cur, tid);
     }
   }
 };
@@ -234,7 +261,17 @@ struct FftPasses {
 template <int LOG2M, int DIR>
 __device__ __forceinline__ void fft_regs_to_lds(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
   PassTwiddles<LOG2M, 0> none;  // pass 0 has unit twiddles
-  FftPasses<LOG2M, DIR, 0>::run(v, s, tw, tid, none);
+  FftPasses<LOG2M, DIR, 0, false>::run(v, s, tw, tid, none);
+}
+
+// Same transform, but the natural-order result stays in registers: v[m] = X[tid + T*m].  Every thread
+// has finished READING the LDS image when this returns to any thread past its next barrier; the image
+// may be overwritten after one __syncthreads() ... in fact the last pass already ends its reads with a
+// barrier, so the caller may write LDS immediately.
+template <int LOG2M, int DIR>
+__device__ __forceinline__ void fft_regs_to_regs(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
+  PassTwiddles<LOG2M, 0> none;
+  FftPasses<LOG2M, DIR, 0, true>::run(v, s, tw, tid, none);
 }
 
 // ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)
@@ -287,6 +324,70 @@ __device__ __forceinline__ void real_pack_load(const float2 *__restrict__ in, fl
       s[lds_pad(M - k)] = make_float2(e.x + o.y, o.x - e.y);
     }
   }
+}
+
+// Register-resident variants: the transform result / input lives in v[m] = Z[tid + T*m]; only the mirrored
+// half (Z[M-k], owned by thread T-tid) goes through LDS, halving the LDS traffic of the packing step.
+template <int LOG2M>
+__device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[16], float2 *s, const float2 *__restrict__ tw,
+                                                       int tid, float2 *__restrict__ out) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  float2 w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w[m] = tw[tid + T * m];  // issued before the exchange
+#pragma unroll
+  for (int m = 8; m < 16; ++m) s[lds_pad(tid + T * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k == 0) {
+      const float2 z0 = v[0], zh = v[8];  // thread 0 owns Z[0] and Z[M/2]
+      out[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
+      out[M / 2] = cconj(zh);
+    } else {
+      const float2 zk = v[m], zm = s[lds_pad(M - k)];
+      const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+      const float2 o = make_float2(d.y, -d.x);
+      const float2 wo = cmul(w[m], o);
+      out[k] = cadd(e, wo);
+      out[M - k] = cconj(csub(e, wo));
+    }
+  }
+}
+
+template <int LOG2M>
+__device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ in, float2 (&v)[16], float2 *s,
+                                                    const float2 *__restrict__ tw, int tid, float scale) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  float2 yk[8], ym[8], w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {  // all loads first: 24 in flight
+    const int k = tid + T * m;
+    yk[m] = in[k];
+    ym[m] = in[k == 0 ? M / 2 : M - k];
+    w[m] = tw[k];
+  }
+  const float hs = 0.5f * scale;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k == 0) {
+      v[0] = make_float2(hs * (yk[0].x + yk[0].y), hs * (yk[0].x - yk[0].y));
+      s[lds_pad(M / 2)] = make_float2(scale * ym[0].x, -scale * ym[0].y);
+    } else {
+      const float2 e = make_float2(hs * (yk[m].x + ym[m].x), hs * (yk[m].y - ym[m].y));
+      const float2 d = make_float2(hs * (yk[m].x - ym[m].x), hs * (yk[m].y + ym[m].y));
+      const float2 o = cmul(cconj(w[m]), d);
+      v[m] = make_float2(e.x - o.y, e.y + o.x);
+      s[lds_pad(M - k)] = make_float2(e.x + o.y, o.x - e.y);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 8; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
+  __syncthreads();
 }
 
 }  // namespace al

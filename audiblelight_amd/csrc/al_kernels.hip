@@ -105,10 +105,11 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
 #pragma unroll
   for (int m = 8; m < 16; ++m) v[m] = make_float2(0.f, 0.f);
 
-  fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
+  fft_regs_to_regs<LOG2M, -1>(v, s, tw, tid);
   const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;  // global (energy partials)
   const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;  // chunk-local spectrum
-  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + hblk * M);
+  real_unpack_store_regs<LOG2M>(v, s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + hblk * M);
+  __syncthreads();  // the reduction below reuses LDS-adjacent scratch only, but keep phases separate
 
   float mx = 0.f, z = 0.f;
   block_reduce3(energy, mx, z, red, tid, T);
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch 
     v[m].x *= g0;
     v[m].y *= g1;
   }
-  fft_regs_to_lds<LOG2M, -1>(v, s, tw, tid);
-  real_unpack_store<LOG2M>(s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M);
+  fft_regs_to_regs<LOG2M, -1>(v, s, tw, tid);
+  real_unpack_store_regs<LOG2M>(v, s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M);
 }
 
 // ------------------------------------------------------------------ 4. frequency-domain accumulate
@@ -229,27 +230,52 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
           h[pp] = make_float2(v.x * gm, v.y * gm);
         }
         const int jbase = k0 - p0 - (PT - 1);  // signal block of anti-diagonal jj is jbase + jj
-        static_for<KT + PT - 1>([&](auto jj_c) {
-          constexpr int jj = decltype(jj_c)::value;
+        // The KT+PT-1 signal blocks are fetched in groups of XG, one group ahead of the FMAs that
+        // consume them (explicit double buffer): the loads are L2 hits with ~1 us latency under load,
+        // and a wave that waits for them one by one is latency-bound, not bandwidth-bound.
+        constexpr int XG = 8, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
+        auto fetch = [&](int jj) -> float2 {
           const int j = jbase + jj;
-          {
-            float2 x = xp[(int64_t)min(max(j, jlo), jhi - 1) * M];  // clamped, unconditional
-            const bool live = (j >= jlo && j < jhi);
-            x.x = live ? x.x : 0.f;
-            x.y = live ? x.y : 0.f;
-            static_for<KT>([&](auto kk_c) {
-              constexpr int kk = decltype(kk_c)::value;
-              constexpr int pp = kk + (PT - 1) - jj;
-              if constexpr (pp >= 0 && pp < PT) {
-                if (packed) {
-                  acc[kk].x = fmaf(x.x, h[pp].x, acc[kk].x);
-                  acc[kk].y = fmaf(x.y, h[pp].y, acc[kk].y);
-                } else {
-                  cfma(acc[kk], x, h[pp]);
+          float2 x = xp[(int64_t)min(max(j, jlo), jhi - 1) * M];  // clamped, unconditional
+          const bool live = (j >= jlo && j < jhi);
+          x.x = live ? x.x : 0.f;
+          x.y = live ? x.y : 0.f;
+          return x;
+        };
+        float2 xa[XG], xb[XG];
+        static_for<XG>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          if constexpr (i < NJ) xa[i] = fetch(i);
+        });
+        static_for<NG>([&](auto g_c) {
+          constexpr int g = decltype(g_c)::value;
+          static_for<XG>([&](auto i_c) {  // prefetch group g+1
+            constexpr int i = decltype(i_c)::value;
+            if constexpr ((g + 1) * XG + i < NJ) xb[i] = fetch((g + 1) * XG + i);
+          });
+          static_for<XG>([&](auto i_c) {  // consume group g
+            constexpr int i = decltype(i_c)::value;
+            constexpr int jj = g * XG + i;
+            if constexpr (jj < NJ) {
+              const float2 x = xa[i];
+              static_for<KT>([&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+                constexpr int pp = kk + (PT - 1) - jj;
+                if constexpr (pp >= 0 && pp < PT) {
+                  if (packed) {
+                    acc[kk].x = fmaf(x.x, h[pp].x, acc[kk].x);
+                    acc[kk].y = fmaf(x.y, h[pp].y, acc[kk].y);
+                  } else {
+                    cfma(acc[kk], x, h[pp]);
+                  }
                 }
-              }
-            });
-          }
+              });
+            }
+          });
+          static_for<XG>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr ((g + 1) * XG + i < NJ) xa[i] = xb[i];
+          });
         });
       }
     }
@@ -290,19 +316,16 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch
     }
   } else {
     const float2 *y = reinterpret_cast<const float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks + k) * M;
-    real_pack_load<LOG2M>(y, s, tw, tid, 1.0f / (float)M);
-    __syncthreads();
     float2 v[16];
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
-    __syncthreads();
-    fft_regs_to_lds<LOG2M, 1>(v, s, tw, tid);
-    // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B)
+    real_pack_load_regs<LOG2M>(y, v, s, tw, tid, 1.0f / (float)M);
+    fft_regs_to_regs<LOG2M, 1>(v, s, tw, tid);
+    // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B); those are
+    // this thread's registers v[8..15] (n = tid + T*m), so the result never goes back through LDS
     const bool pair_ok = (((ev.out_off + (int64_t)c * ev.len) & 1) == 0);
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int i = tid + T * m;  // complex index inside the kept half
-      const float2 z = s[lds_pad(M / 2 + i)];
+      const float2 z = v[8 + m];
       const int t = tbase + 2 * i;
       const float x0 = t < ev.valid_len ? z.x : 0.f;
       const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
@@ -376,23 +399,71 @@ __global__ __launch_bounds__(64) void k_event_levels(al_batch b) {
 }
 
 // ------------------------------------------------------------------ 7. mixdown
+// One workgroup per (capsule, tile of m.tile = 4096 samples).  A thread owns 4 runs of 4 consecutive
+// samples (16 accumulators); events that overlap the tile are walked in insertion order with their slot
+// scalars in SGPRs, each adding scale * x with dword-aligned 16-byte loads (an event starts at an
+// arbitrary sample, so its rows are not 16-byte aligned against the scene).
+struct __attribute__((packed, aligned(4))) f4u {
+  float x, y, z, w;
+};
+
 __global__ __launch_bounds__(256) void k_mixdown(al_mix m) {
   const int tile = blockIdx.x, c = blockIdx.y;
   const int lo = m.tile_ptr[tile], hi = m.tile_ptr[tile + 1];
   const int t_begin = tile * m.tile;
-  const int t_end = min(t_begin + m.tile, m.n_samples);
   float *row = m.scene + (int64_t)c * m.n_samples;
-  for (int t = t_begin + threadIdx.x; t < t_end; t += 256) {
-    float acc = m.accumulate ? row[t] : 0.f;
-    for (int q = lo; q < hi; ++q) {
-      const int sl = m.tile_events[q];
-      const int rel = t - m.slot_start[sl];
-      if (c < m.slot_rows[sl] && rel >= 0 && rel < m.slot_count[sl]) {
-        const float x = m.spatial[m.slot_src[sl] + (int64_t)c * m.slot_len[sl] + rel];
-        acc = fmaf(m.event_scale[m.slot_event[sl]], x, acc);
+  constexpr int RUNS = 4;                       // m.tile == 4 * 256 * RUNS
+  float4 acc[RUNS];
+  const bool whole = (t_begin + m.tile <= m.n_samples) && ((m.n_samples & 3) == 0);  // workgroup-uniform
+#pragma unroll
+  for (int r = 0; r < RUNS; ++r) {
+    const int t = t_begin + 4 * (threadIdx.x + 256 * r);
+    acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m.accumulate) {
+      if (whole) {
+        acc[r] = *reinterpret_cast<const float4 *>(row + t);
+      } else {
+        if (t < m.n_samples) acc[r].x = row[t];
+        if (t + 1 < m.n_samples) acc[r].y = row[t + 1];
+        if (t + 2 < m.n_samples) acc[r].z = row[t + 2];
+        if (t + 3 < m.n_samples) acc[r].w = row[t + 3];
       }
     }
-    row[t] = acc;
+  }
+  for (int q = lo; q < hi; ++q) {
+    const int sl = m.tile_events[q];
+    if (c >= m.slot_rows[sl]) continue;
+    const int start = m.slot_start[sl], count = m.slot_count[sl];
+    const float scale = m.event_scale[m.slot_event[sl]];
+    const float *x = m.spatial + m.slot_src[sl] + (int64_t)c * m.slot_len[sl];
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {
+      const int rel = t_begin + 4 * (threadIdx.x + 256 * r) - start;
+      if (rel >= 0 && rel + 3 < count) {
+        const f4u v = *reinterpret_cast<const f4u *>(x + rel);
+        acc[r].x = fmaf(scale, v.x, acc[r].x);
+        acc[r].y = fmaf(scale, v.y, acc[r].y);
+        acc[r].z = fmaf(scale, v.z, acc[r].z);
+        acc[r].w = fmaf(scale, v.w, acc[r].w);
+      } else if (rel > -4 && rel < count) {  // run straddles the start or the end of the slot
+        if (rel >= 0 && rel < count) acc[r].x = fmaf(scale, x[rel], acc[r].x);
+        if (rel + 1 >= 0 && rel + 1 < count) acc[r].y = fmaf(scale, x[rel + 1], acc[r].y);
+        if (rel + 2 >= 0 && rel + 2 < count) acc[r].z = fmaf(scale, x[rel + 2], acc[r].z);
+        if (rel + 3 >= 0 && rel + 3 < count) acc[r].w = fmaf(scale, x[rel + 3], acc[r].w);
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RUNS; ++r) {
+    const int t = t_begin + 4 * (threadIdx.x + 256 * r);
+    if (whole) {
+      *reinterpret_cast<float4 *>(row + t) = acc[r];
+    } else {
+      if (t < m.n_samples) row[t] = acc[r].x;
+      if (t + 1 < m.n_samples) row[t + 1] = acc[r].y;
+      if (t + 2 < m.n_samples) row[t + 2] = acc[r].z;
+      if (t + 3 < m.n_samples) row[t + 3] = acc[r].w;
+    }
   }
 }
 
@@ -709,7 +780,9 @@ int al_render_batch(const al_batch *b, al_stream_t stream) {
 
 int al_mixdown(const al_mix *m, al_stream_t stream) {
   if (!m || m->n_capsules <= 0 || m->n_samples <= 0 || m->tile <= 0) return fail(AL_E_BADARG, "bad mixdown arguments");
+  if (m->tile != 4096) return fail(AL_E_BADARG, "mixdown tile must be 4096 samples");
   if (m->n_tiles != (m->n_samples + m->tile - 1) / m->tile) return fail(AL_E_BADARG, "n_tiles != ceil(n_samples / tile)");
+  if (((uintptr_t)m->scene & 15) != 0) return fail(AL_E_BADARG, "scene buffer must be 16-byte aligned");
   hipLaunchKernelGGL(al::k_mixdown, dim3(m->n_tiles, m->n_capsules), dim3(256), 0, (hipStream_t)stream, *m);
   return check_launch("k_mixdown");
 }

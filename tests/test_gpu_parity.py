@@ -84,7 +84,7 @@ def test_full_scene_golden(gpu, planning, golden):
         assert_close(res.spatial_audio(i), golden[f"g8_spatial{i}"])
     starts = [float(s[2]) for s in golden["g8_specs"]]
     mix = planning.plan_mixdown(starts, [s + len(c) / sr for s, c in zip(starts, clips)], [len(c) for c in clips],
-                                [C] * 5, pl.events["out_off"], list(range(5)), dur, sr, C, tile=1024)
+                                [C] * 5, pl.events["out_off"], list(range(5)), dur, sr, C)
     amb = golden["g8_ambience"].astype(np.float32)
     amb_dev = gpu.mem.upload(amb.reshape(-1))
     stats = gpu.mem.download(gpu.row_stats(amb_dev, 1, amb.size)).reshape(-1, 4)

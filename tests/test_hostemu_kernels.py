@@ -95,7 +95,7 @@ def test_emu_full_scene_with_ambience(emu, golden):
     starts = [float(s[2]) for s in golden["g8_specs"]]
     ends = [s + len(c) / sr for s, c in zip(starts, clips)]
     mix = planning.plan_mixdown(starts, ends, [len(c) for c in clips], [C] * 5, pl.events["out_off"],
-                                list(range(5)), dur, sr, C, tile=1024)
+                                list(range(5)), dur, sr, C)
     amb = golden["g8_ambience"].astype(np.float32)
     amb_dev = emu.mem.upload(amb.reshape(-1))
     stats = emu.mem.download(emu.row_stats(amb_dev, 1, amb.size)).reshape(-1, 4)

@@ -72,7 +72,7 @@ __global__ void k_twiddle_init(float2 *tw, int m) {
 
 // ------------------------------------------------------------------ 1. IR partition spectra
 template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M)) void k_ir_spectra(al_batch b) {
+__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_ir_spectra(al_batch b) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   __shared__ float2 s[fft_lds_elems(LOG2M)];
   __shared__ float red[48];
@@ -146,7 +146,7 @@ __device__ __forceinline__ float stream_envelope(const float *__restrict__ w, in
 }
 
 template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch b) {
+__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_signal_spectra(al_batch b) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   __shared__ float2 s[fft_lds_elems(LOG2M)];
   const int tid = threadIdx.x;
@@ -193,10 +193,38 @@ __global__ __launch_bounds__(fft_threads(LOG2M)) void k_signal_spectra(al_batch 
 // registers and the KT+PT-1 signal blocks on its anti-diagonals are loaded ONCE each, so a pair
 // costs KT+2*PT-1 loads for KT*PT complex FMAs (static register indices throughout).
 // Bin 0 packs (DC, Nyquist): two independent real products.
-template <int KT, int PT>
+// VB = bins per thread (1: float2 accesses, 2: float4 accesses of two adjacent bins).
+template <int VB> struct BinVec;
+template <> struct BinVec<1> {
+  float2 a;
+  __device__ __forceinline__ static BinVec zero() { return BinVec{make_float2(0.f, 0.f)}; }
+  __device__ __forceinline__ static BinVec load(const float2 *p) { return BinVec{*p}; }
+  __device__ __forceinline__ void store(float2 *p) const { *p = a; }
+  __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; }
+  __device__ __forceinline__ void fma(const BinVec &x, const BinVec &h, bool packed) {
+    if (packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
+  }
+};
+template <> struct BinVec<2> {
+  float2 a, c;
+  __device__ __forceinline__ static BinVec zero() { return BinVec{make_float2(0.f, 0.f), make_float2(0.f, 0.f)}; }
+  __device__ __forceinline__ static BinVec load(const float2 *p) {
+    const float4 v = *reinterpret_cast<const float4 *>(p);
+    return BinVec{make_float2(v.x, v.y), make_float2(v.z, v.w)};
+  }
+  __device__ __forceinline__ void store(float2 *p) const { *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, c.x, c.y); }
+  __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; c.x *= g; c.y *= g; }
+  __device__ __forceinline__ void fma(const BinVec &x, const BinVec &h, bool packed) {
+    if (packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
+    cfma(c, x.c, h.c);
+  }
+};
+
+template <int KT, int PT, int VB>
 __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
+  using V = BinVec<VB>;
   const int M = 1 << b.log2_block;
-  const int f = blockIdx.x * 256 + threadIdx.x;
+  const int f = (blockIdx.x * 256 + threadIdx.x) * VB;
   const int c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
@@ -204,12 +232,12 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
   const int K = ev.n_blocks, P = b.n_partitions;
-  const bool packed = (f == 0);
+  const bool packed = (f == 0);  // bin 0 holds (DC, Nyquist): two independent real products
 
   for (int k0 = 0; k0 < K; k0 += KT) {
-    float2 acc[KT];
+    V acc[KT];
 #pragma unroll
-    for (int kk = 0; kk < KT; ++kk) acc[kk] = make_float2(0.f, 0.f);
+    for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
     for (int l = 0; l < ev.n_streams; ++l) {
       const al_stream st = b.streams[ev.stream0 + l];
       const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;  // non-zero signal blocks [jlo, jhi)
@@ -221,73 +249,62 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
       const float2 *hp = H + (((int64_t)(st.emitter - b.emitter0) * b.n_capsules + c) * P) * M + f;
       const float2 *xp = X + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
       for (int p0 = plo; p0 <= phi; p0 += PT) {
-        float2 h[PT];
+        V h[PT];
 #pragma unroll
         for (int pp = 0; pp < PT; ++pp) {
           // unconditional load at a clamped partition, zeroed by the select: keeps all PT loads in flight
-          const float2 v = hp[(int64_t)min(p0 + pp, phi) * M];
-          const float gm = (p0 + pp <= phi) ? g : 0.f;
-          h[pp] = make_float2(v.x * gm, v.y * gm);
+          h[pp] = V::load(hp + (int64_t)min(p0 + pp, phi) * M);
+          h[pp].scale((p0 + pp <= phi) ? g : 0.f);
         }
         const int jbase = k0 - p0 - (PT - 1);  // signal block of anti-diagonal jj is jbase + jj
         // The KT+PT-1 signal blocks are fetched in groups of XG, one group ahead of the FMAs that
         // consume them (explicit double buffer): the loads are L2 hits with ~1 us latency under load,
         // and a wave that waits for them one by one is latency-bound, not bandwidth-bound.
-        constexpr int XG = 8, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
-        auto fetch = [&](int jj) -> float2 {
+        constexpr int XG = 8 / VB, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
+        auto fetch = [&](int jj) -> V {
           const int j = jbase + jj;
-          float2 x = xp[(int64_t)min(max(j, jlo), jhi - 1) * M];  // clamped, unconditional
-          const bool live = (j >= jlo && j < jhi);
-          x.x = live ? x.x : 0.f;
-          x.y = live ? x.y : 0.f;
+          V x = V::load(xp + (int64_t)min(max(j, jlo), jhi - 1) * M);  // clamped, unconditional
+          x.scale((j >= jlo && j < jhi) ? 1.f : 0.f);
           return x;
         };
-        float2 xa[XG], xb[XG];
+        V xa[XG], xb[XG];
         static_for<XG>([&](auto i_c) {
           constexpr int i = decltype(i_c)::value;
           if constexpr (i < NJ) xa[i] = fetch(i);
         });
         static_for<NG>([&](auto g_c) {
-          constexpr int g = decltype(g_c)::value;
+          constexpr int g_ = decltype(g_c)::value;
           static_for<XG>([&](auto i_c) {  // prefetch group g+1
             constexpr int i = decltype(i_c)::value;
-            if constexpr ((g + 1) * XG + i < NJ) xb[i] = fetch((g + 1) * XG + i);
+            if constexpr ((g_ + 1) * XG + i < NJ) xb[i] = fetch((g_ + 1) * XG + i);
           });
           static_for<XG>([&](auto i_c) {  // consume group g
             constexpr int i = decltype(i_c)::value;
-            constexpr int jj = g * XG + i;
+            constexpr int jj = g_ * XG + i;
             if constexpr (jj < NJ) {
-              const float2 x = xa[i];
               static_for<KT>([&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
                 constexpr int pp = kk + (PT - 1) - jj;
-                if constexpr (pp >= 0 && pp < PT) {
-                  if (packed) {
-                    acc[kk].x = fmaf(x.x, h[pp].x, acc[kk].x);
-                    acc[kk].y = fmaf(x.y, h[pp].y, acc[kk].y);
-                  } else {
-                    cfma(acc[kk], x, h[pp]);
-                  }
-                }
+                if constexpr (pp >= 0 && pp < PT) acc[kk].fma(xa[i], h[pp], packed);
               });
             }
           });
           static_for<XG>([&](auto i_c) {
             constexpr int i = decltype(i_c)::value;
-            if constexpr ((g + 1) * XG + i < NJ) xa[i] = xb[i];
+            if constexpr ((g_ + 1) * XG + i < NJ) xa[i] = xb[i];
           });
         });
       }
     }
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
-      if (k0 + kk < K) Y[((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f] = acc[kk];
+      if (k0 + kk < K) acc[kk].store(Y + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f);
   }
 }
 
 // ------------------------------------------------------------------ 5. block synthesis
 template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M)) void k_block_synthesis(al_batch b) {
+__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_block_synthesis(al_batch b) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   __shared__ float2 s[fft_lds_elems(LOG2M)];
   __shared__ float red[48];
@@ -738,17 +755,25 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream) {
 int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->n_emitters <= 0) return AL_OK;
-  const dim3 grid((1 << b->log2_block) / 256, b->n_capsules, b->n_events);
-  // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers
+  // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers.
+  // flags bits 8..11 select an experimental variant (0 = default).
+  const int variant = (b->flags >> 8) & 15;
   const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
-  if (wide_k && wide_p)
-    hipLaunchKernelGGL((al::k_spectral_mac<24, 12>), grid, dim3(256), 0, (hipStream_t)stream, *b);
-  else if (wide_k)
-    hipLaunchKernelGGL((al::k_spectral_mac<24, 4>), grid, dim3(256), 0, (hipStream_t)stream, *b);
-  else if (wide_p)
-    hipLaunchKernelGGL((al::k_spectral_mac<8, 12>), grid, dim3(256), 0, (hipStream_t)stream, *b);
-  else
-    hipLaunchKernelGGL((al::k_spectral_mac<8, 4>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+  const int bins = 1 << b->log2_block;
+#define AL_MAC(KT_, PT_, VB_) \
+  hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \
+                     (hipStream_t)stream, *b)
+  if (variant == 1) AL_MAC(12, 12, 1);
+  else if (variant == 2) AL_MAC(12, 12, 2);
+  else if (variant == 3) AL_MAC(8, 12, 2);
+  else if (variant == 4) AL_MAC(24, 12, 2);
+  else if (variant == 5) AL_MAC(8, 12, 1);
+  else if (variant == 6) AL_MAC(24, 12, 1);
+  else if (wide_k && wide_p && bins >= 512) AL_MAC(12, 12, 2);  // fastest on cfg2 (profiles/r01_mac_variants.txt)
+  else if (wide_k) AL_MAC(24, 4, 1);
+  else if (wide_p) AL_MAC(8, 12, 1);
+  else AL_MAC(8, 4, 1);
+#undef AL_MAC
   return check_launch("k_spectral_mac");
 }
 

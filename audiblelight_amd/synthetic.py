@@ -14,7 +14,7 @@ CONFIGS = {
     "cfg2": dict(sr=48000, C=32, E=64, N=1, Lir=96000, La=192000, T=60.0),
     "cfg3": dict(sr=48000, C=32, E=16, N=32, Lir=96000, La=372000, T=60.0),
     "cfg4": dict(sr=48000, C=32, E=32, N=1, Lir=48000, La=192000, T=30.0),
-    "cfg5": dict(sr=48000, C=64, E=128, N=1, Lir=192000, La=192000, T=60.0),
+    "cfg5": dict(sr=48000, C=64, E=128, N=1, Lir=192000, La=192000, T=60.0, ambience="white", fx=True),
 }
 
 
@@ -29,6 +29,15 @@ class SyntheticScene:
     irs: np.ndarray             # (C, sum N, Lir) float32
     specs: List[EventSpec]
     starts: List[float]
+    ambience_beta: object = None  # noise colour of the scene ambience (cfg5: "white"), None = no ambience
+
+    def describe(self) -> str:
+        sp = self.specs[0]
+        kind = f"{sp.n_emitters}-IR moving" if sp.is_moving else "static"
+        return (f"{self.name}: 1 scene/GPU/step, {self.n_capsules} capsules, {len(self.specs)} {kind} events, "
+                f"{self.ir_len / self.sr:g} s RIR, {len(self.clips[0]) / self.sr:g} s clips, {self.duration:g} s scene @ "
+                f"{self.sr} Hz" + (f", {self.ambience_beta} ambience + Gain/Invert FX folded into the clip gain"
+                                   if self.ambience_beta is not None else ""))
 
     @property
     def ends(self):
@@ -58,8 +67,14 @@ def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, **o
             h = rng.standard_normal((C, Lir), dtype=np.float32) * decay
             h[np.arange(C), rng.integers(48, min(960, Lir), size=C)] += 1.0
             irs[:, e * N + n, :] = h
+        gain = 1.0
+        if cfg.get("fx"):
+            # [Gain(gain_db ~ U(-10, 10)), Invert] then peak normalisation (event.py:529-536) fold into one
+            # scalar on the already peak-normalised clip: -g / (g * 1 + tiny)
+            g = 10.0 ** (float(rng.uniform(-10, 10)) / 20.0)
+            gain = float(-g / (g + np.finfo(np.float32).tiny))
         specs.append(EventSpec(n_samples=La, n_emitters=N, snr=float(rng.uniform(5, 30)), emitter0=e * N,
-                               is_moving=N > 1, duration=La / sr, ref_db=-65.0))
+                               is_moving=N > 1, duration=La / sr, ref_db=-65.0, gain=gain))
         starts.append(float(rng.uniform(0, max(T - La / sr, 0.0))))
     return SyntheticScene(name=name, sr=sr, duration=T, n_capsules=C, ir_len=Lir, clips=clips, irs=irs, specs=specs,
-                          starts=starts)
+                          starts=starts, ambience_beta=cfg.get("ambience"))

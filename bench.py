@@ -1,12 +1,13 @@
 #!/usr/bin/env python
-"""Headline benchmark: rendered scene-seconds per second on the cfg2 workload of BASELINE.json.
+"""Headline benchmark: rendered scene-seconds per second (BASELINE.json metric) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config cfg2]
 
-One "step" = one full pass of the hot path over one 60 s scene (32 capsules, 64 events, 2 s RIRs,
-48 kHz): render_audio_for_all_scene_events + generate_scene_audio_from_events equivalents, inputs
-already resident in HBM.  For N > 1 every rank renders its own scenes (weak scaling, no data-path
-collective); rank 0 prints ONE JSON line.
+One "step" = one full pass of the hot path over one synthetic scene of the chosen config (default
+cfg2: 60 s scene, 32 capsules, 64 static events, 2 s RIRs, 48 kHz): the equivalents of
+render_audio_for_all_scene_events + generate_scene_audio_from_events with clips, IRs and tables
+already resident in HBM.  For N > 1 every rank renders its own scene (weak scaling, no data-path
+collective; the optional end-of-job gather is timed separately); rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -20,41 +21,61 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
+METRIC = "rendered scene-seconds/sec @48kHz, 32-ch mic, 64 events, 2s RIR; 1/2/4/8 GPU"
 
 
-def cpu_baseline(scene, n_events: int):
+def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
     """Time the float64 numpy/scipy oracle (kind "port") on a bounded sample of the same workload."""
     from oracle import synth_oracle as orc
 
     t0 = time.perf_counter()
-    spatials = []
+    spatials, work, full_work = [], 0, 0
     for i in range(n_events):
         sp = scene.specs[i]
-        h = scene.irs[:, sp.emitter0: sp.emitter0 + sp.n_emitters, :].astype(np.float64)
+        n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
+        h = scene.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
         spatials.append(orc.render_event(scene.clips[i], h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr)["spatial"])
+        work += n_used
+    for sp in scene.specs:
+        full_work += max(sp.n_emitters, 1)
     t_events = time.perf_counter() - t0
     t0 = time.perf_counter()
     orc.mix_scene(spatials, list(zip(scene.starts[:n_events], scene.ends[:n_events])), scene.duration, scene.sr,
                   keep_padded=True)
     t_mix = time.perf_counter() - t0
-    per_event = (t_events + t_mix) / n_events
-    total = per_event * len(scene.specs)
+    total = t_events * full_work / max(work, 1) + t_mix * len(scene.specs) / n_events
+    moving = any(sp.is_moving for sp in scene.specs)
     return dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port",
-                sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene (render_event + mixdown with "
-                       f"per-event padded copies), {t_events + t_mix:.1f} s measured, scaled linearly in events")
+                sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene"
+                       + (f" with {n_irs_cap} of {scene.specs[0].n_emitters} IRs each" if moving else "")
+                       + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured, "
+                         f"scaled linearly in events x IRs")
+
+
+def load_pmc_traffic(config: str, log2_block: int):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json)."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+        return table.get(f"{config}/log2_block={log2_block}")
+    except Exception:
+        return None
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2")
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--cpu-events", type=int, default=6, help="events timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
     args = ap.parse_args()
 
     import torch
@@ -74,14 +95,23 @@ def main():
     r = engine.Renderer()
     pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
     batch = r.prepare(pl, scene.clips, scene.irs, chunk_events=args.chunk_events)
-    mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips],
-                                     [scene.n_capsules] * len(scene.clips), pl.events["out_off"],
-                                     list(range(len(scene.clips))), scene.duration, scene.sr, scene.n_capsules)
-    mix = r.prepare_mixdown(mix_plan, batch.result())
+    n_ev = len(scene.clips)
+    mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
+                                     pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)
+    ambience = []
+    if scene.ambience_beta is not None:  # cfg5: white ambience generated on the device, once (inputs resident)
+        from audiblelight_amd import ambience as amb
+        from audiblelight_amd.synthesize import _ambience_on_device
+
+        a = amb.Ambience(channels=scene.n_capsules, duration=scene.duration, alias="bench", noise=scene.ambience_beta,
+                         ref_db=-65, sample_rate=scene.sr)
+        ambience = [_ambience_on_device(r, a, (scene.n_capsules, mix_plan.n_samples))]
+    mix = r.prepare_mixdown(mix_plan, batch.result(), ambience)
     stages = list(batch.STAGES) + ["al_mixdown"]
+    chunked = len(batch.descs) > 1
 
     def step(events=None):
-        if len(batch.descs) > 1:
+        if chunked:
             batch.run()
             mix.run()
             return
@@ -108,7 +138,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(ev[k])
+        step(None if chunked else ev[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
@@ -118,7 +148,7 @@ def main():
         elapsed = float(t.item())
     batch.result().check_finite()
 
-    if len(batch.descs) > 1:
+    if chunked:
         kernel_ms = {"al_render_batch+al_mixdown": elapsed / args.steps * 1e3}
     else:
         kernel_ms = {name: float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
@@ -126,26 +156,36 @@ def main():
     dominant = max(kernel_ms, key=kernel_ms.get)
     algo_bytes = scene.algorithmic_bytes()
     achieved = algo_bytes / (kernel_ms[dominant] * 1e-3) / 1e9
+    pmc = load_pmc_traffic(scene.name, pl.log2_block) if args.scale == 1.0 else None
     out = {
-        "metric": "rendered scene-seconds/sec @48kHz, 32-ch mic, 64 events, 2s RIR",
+        "metric": METRIC,
         "value": world * args.steps * scene.duration / elapsed,
         "unit": "scene-seconds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{scene.name}: 1 scene/GPU/step, {scene.n_capsules} capsules, {len(scene.specs)} static events, "
-                               f"{scene.ir_len / scene.sr:g} s RIR, {scene.clips[0].size / scene.sr:g} s clips, "
-                               f"{scene.duration:g} s scene @ {scene.sr} Hz",
-                   "scale": args.scale, "log2_block": pl.log2_block, "scenes_per_step_per_gpu": 1,
-                   "chunk_events": args.chunk_events},
+        "config": {"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
+                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms},
+                     "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": (pmc or {}).get(dominant),
+                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
+                     "hbm_bytes_per_launch_pmc": pmc},
     }
+    if args.gather and world > 1:
+        from audiblelight_amd import distributed
+
+        torch.cuda.synchronize()
+        g0 = time.perf_counter()
+        scene_t = mix.scene[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1)
+        distributed.gather_buffers({rank: scene_t}, world, dst=0)
+        torch.cuda.synchronize()
+        out["gather"] = {"ms": (time.perf_counter() - g0) * 1e3, "bytes_per_rank": int(scene_t.numel() * 4),
+                         "note": "RCCL gather of one (C, T) float32 scene per rank to rank 0 (includes the D2H on the root)"}
     if rank == 0:
         if world == 1 and args.cpu_events > 0:
-            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, len(scene.specs)))
+            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

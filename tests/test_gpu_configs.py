@@ -1,0 +1,88 @@
+"""BASELINE.json configs[2..4] as parity cases (reduced sizes the oracle finishes in seconds):
+moving sources (cfg3), a multi-scene batch in one launch sequence (cfg4), 64 capsules + ambience + folded FX (cfg5)."""
+import numpy as np
+import pytest
+
+from oracle import synth_oracle as orc
+from tests.conftest import rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from audiblelight_amd import engine
+
+    return engine.Renderer()
+
+
+def oracle_event(sc, i):
+    sp = sc.specs[i]
+    h = sc.irs[:, sp.emitter0: sp.emitter0 + sp.n_emitters, :].astype(np.float64)
+    return orc.render_event(sc.clips[i] * np.float32(sp.gain), h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, sc.sr)["spatial"]
+
+
+def test_cfg3_moving_sources(gpu):
+    from audiblelight_amd import plan as planning, synthetic
+
+    sc = synthetic.make_scene("cfg3", scale=0.05, E=4)            # 4 events x 32 waypoints, 32 capsules
+    pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)
+    res = gpu.render(pl, sc.clips, sc.irs)
+    res.check_finite()
+    assert int(pl.streams["n_j"].max()) < int(pl.events["n_blocks"].max())   # cross-fade windows are sparse
+    for i in (0, 3):
+        want = oracle_event(sc, i)
+        got = res.spatial_audio(i)
+        assert rel_rms(got, want) < TOL
+        assert np.mean(np.abs(got)) == pytest.approx(10 ** ((-65 + sc.specs[i].snr) / 20), rel=1e-5)
+
+
+def test_cfg4_scene_batch_in_one_launch(gpu):
+    """Several independent scenes share one launch sequence: events concatenated, IR columns offset."""
+    from audiblelight_amd import plan as planning, synthetic
+
+    scenes = [synthetic.make_scene("cfg4", scene_index=i, scale=0.04, E=5, C=8) for i in range(3)]
+    specs, clips, col = [], [], 0
+    for sc in scenes:
+        for sp, clip in zip(sc.specs, sc.clips):
+            specs.append(planning.EventSpec(sp.n_samples, sp.n_emitters, sp.snr, emitter0=col + sp.emitter0, ref_db=sp.ref_db))
+            clips.append(clip)
+        col += sc.irs.shape[1]
+    irs = np.concatenate([sc.irs for sc in scenes], axis=1)
+    pl = planning.plan_batch(specs, 8, scenes[0].ir_len, scenes[0].sr)
+    res = gpu.render(pl, clips, irs)
+    e0 = 0
+    for sc in scenes:
+        n = len(sc.specs)
+        mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [8] * n,
+                                    pl.events["out_off"][e0: e0 + n], list(range(e0, e0 + n)), sc.duration, sc.sr, 8)
+        got = gpu.mem.download(gpu.mixdown(mix, res))[: 8 * mix.n_samples].reshape(8, -1)
+        want = orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
+                             keep_padded=False)["scene"]
+        assert rel_rms(got, want) < TOL
+        e0 += n
+
+
+def test_cfg5_64ch_ambience_and_folded_fx(gpu):
+    from audiblelight_amd import ambience as amb, plan as planning, synthetic
+    from audiblelight_amd import synthesize as syn
+
+    syn.set_renderer(gpu)
+    try:
+        sc = synthetic.make_scene("cfg5", scale=0.03, E=6)
+        assert sc.n_capsules == 64 and all(sp.gain < 0 for sp in sc.specs)    # Invert folded into the gain
+        pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)
+        res = gpu.render(pl, sc.clips, sc.irs)
+        n = len(sc.specs)
+        mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [64] * n, pl.events["out_off"],
+                                    list(range(n)), sc.duration, sc.sr, 64)
+        a = amb.Ambience(channels=64, duration=sc.duration, alias="a", noise="white", ref_db=-65, sample_rate=sc.sr)
+        dev = syn._ambience_on_device(gpu, a, (64, mix.n_samples))
+        got = gpu.mem.download(gpu.mixdown(mix, res, [dev]))[: 64 * mix.n_samples].reshape(64, -1)
+        noise = orc.ambience_noise(0, 64, sc.duration, sc.sr)
+        want = orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
+                             ambiences=[(noise, -65)], keep_padded=False)["scene"]
+        assert rel_rms(got, want) < TOL
+    finally:
+        syn.set_renderer(None)

@@ -30,7 +30,7 @@ def test_cfg3_moving_sources(gpu):
     pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)
     res = gpu.render(pl, sc.clips, sc.irs)
     res.check_finite()
-    assert int(pl.streams["n_j"].max()) < int(pl.events["n_blocks"].max())   # cross-fade windows are sparse
+    assert int(pl.streams["n_j"].sum()) < 32 * 4 * int(pl.events["n_blocks"].max())   # cross-fade windows are sparse
     for i in (0, 3):
         want = oracle_event(sc, i)
         got = res.spatial_audio(i)

@@ -71,6 +71,8 @@ SYMBOLS = {
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_event_stats": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_event_levels_from_stats": (ct.c_int, [ct.POINTER(AlBatch), ct.c_int32, _S]),
     "al_render_batch": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_mixdown": (ct.c_int, [ct.POINTER(AlMix), _S]),
     "al_scale_rows": (ct.c_int, [_P, ct.c_int64, _P, _S]),

@@ -381,32 +381,48 @@ __global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_block_synthesis(al_ba
 // ------------------------------------------------------------------ 6. event levels
 // Composite of apply_snr (synthesize.py:40-49) and db_to_multiplier (synthesize.py:52-68) as chained
 // at synthesize.py:594-599, evaluated in float64 from the deterministic partial statistics.
-__global__ __launch_bounds__(64) void k_event_levels(al_batch b) {
+// mode 0: reduce + law (single GPU); 1: reduce only; 2: law only, from event_stats, with `total_capsules` rows
+__global__ __launch_bounds__(64) void k_event_levels(al_batch b, int mode, int total_capsules) {
   const int e = b.event0 + blockIdx.x;
   const al_event ev = b.events[e];
   const int lane = threadIdx.x;
-  const int n = b.n_capsules * ev.n_blocks;
-  const float *pp = b.partials + 4 * (int64_t)ev.part_base;
+  double *o = b.event_stats + 4 * (int64_t)e;
   double sum = 0.0, bad = 0.0;
   float mx = 0.f;
-  for (int i = lane; i < n; i += 64) {
-    sum += (double)pp[4 * i];
-    mx = fmaxf(mx, pp[4 * i + 1]);
-    bad += (double)pp[4 * i + 2];
-  }
+  if (mode != 2) {
+    const int n = b.n_capsules * ev.n_blocks;
+    const float *pp = b.partials + 4 * (int64_t)ev.part_base;
+    for (int i = lane; i < n; i += 64) {
+      sum += (double)pp[4 * i];
+      mx = fmaxf(mx, pp[4 * i + 1]);
+      bad += (double)pp[4 * i + 2];
+    }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    sum += __shfl_down(sum, off, 64);
-    mx = fmaxf(mx, __shfl_down(mx, off, 64));
-    bad += __shfl_down(bad, off, 64);
+    for (int off = 32; off > 0; off >>= 1) {
+      sum += __shfl_down(sum, off, 64);
+      mx = fmaxf(mx, __shfl_down(mx, off, 64));
+      bad += __shfl_down(bad, off, 64);
+    }
   }
   if (lane == 0) {
+    if (mode == 2) {
+      sum = o[0];
+      mx = (float)o[1];
+      bad = o[2];
+    }
+    if (mode == 1) {
+      o[0] = sum;
+      o[1] = (double)mx;
+      o[2] = bad;
+      o[3] = 0.0;
+      return;
+    }
+    const double rows = mode == 2 ? (double)total_capsules : (double)b.n_capsules;
     const double snr = (double)ev.snr;
     const double peak = fmax((double)mx, 1e-15);
     const double s1 = snr / peak;                                   // apply_snr
-    const double mean_abs = fabs(s1) * sum / ((double)b.n_capsules * (double)ev.len);
+    const double mean_abs = fabs(s1) * sum / (rows * (double)ev.len);
     const double s2 = pow(10.0, ((double)ev.ref_db + snr) / 20.0) / (mean_abs + 2.2250738585072014e-308);
-    double *o = b.event_stats + 4 * (int64_t)e;
     o[0] = sum;
     o[1] = (double)mx;
     o[2] = bad;
@@ -789,8 +805,23 @@ int al_block_synthesis(const al_batch *b, al_stream_t stream) {
 int al_event_levels(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0) return AL_OK;
-  hipLaunchKernelGGL(al::k_event_levels, dim3(b->n_events), dim3(64), 0, (hipStream_t)stream, *b);
+  hipLaunchKernelGGL(al::k_event_levels, dim3(b->n_events), dim3(64), 0, (hipStream_t)stream, *b, 0, 0);
   return check_launch("k_event_levels");
+}
+
+int al_event_stats(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_events <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_event_levels, dim3(b->n_events), dim3(64), 0, (hipStream_t)stream, *b, 1, 0);
+  return check_launch("k_event_levels(stats)");
+}
+
+int al_event_levels_from_stats(const al_batch *b, int32_t total_capsules, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (total_capsules < b->n_capsules) return fail(AL_E_BADARG, "total_capsules < n_capsules");
+  if (b->n_events <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_event_levels, dim3(b->n_events), dim3(64), 0, (hipStream_t)stream, *b, 2, total_capsules);
+  return check_launch("k_event_levels(law)");
 }
 
 int al_render_batch(const al_batch *b, al_stream_t stream) {

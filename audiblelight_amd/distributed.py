@@ -96,3 +96,72 @@ def render_scenes(n_scenes: int, render_fn: Callable[[int], "object"], gather: b
     if not gather or world == 1:
         return {i: (v if isinstance(v, np.ndarray) else v.cpu().numpy()) for i, v in local.items()} if world == 1 else local
     return gather_buffers(local, n_scenes, dst=dst)
+
+
+# ----------------------------------------------------------------------------- one scene, capsules sharded
+def capsule_slice(n_capsules: int, rank: int, world_size: int) -> slice:
+    """Contiguous capsule rows owned by ``rank`` (IR bytes dominate and are capsule-separable)."""
+    per = -(-n_capsules // world_size)
+    return slice(min(rank * per, n_capsules), min((rank + 1) * per, n_capsules))
+
+
+def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_capsules: int, sample_rate: float,
+                           log2_block: Optional[int] = None):
+    """Render one microphone of one scene with this rank's capsules only.
+
+    Every rank convolves all events against its own capsule rows of the IR tensor (clips are replicated: small).
+    The per-event level (one scalar from sum|x| and max|x| over ALL capsules, synthesize.py:594-599) is the
+    only coupling: one all-reduce of E x {SUM, MAX, SUM} doubles between block synthesis and the level law.
+    Returns the RenderResult of the local capsules (event_scale identical on every rank).
+    """
+    import ctypes as ct
+
+    import torch
+    import torch.distributed as dist
+
+    from . import plan as planning
+
+    pl = planning.plan_batch(specs, irs_local.shape[0], irs_local.shape[2], sample_rate, log2_block=log2_block)
+    batch = renderer.prepare(pl, clips, irs_local)
+    lib, stream = renderer.lib, renderer.mem.stream()
+    desc = batch.descs[0]
+    lib.call("al_ir_spectra", ct.byref(desc), stream)
+    # emitter gains are a mean over ALL capsules as well (normalize_irs, synthesize.py:404-428): reduce the energies
+    gains = _allreduce_emitter_gains(renderer, batch, total_capsules)
+    batch.bufs["emitter_gain"][: len(gains)] = gains
+    for name in ("al_signal_spectra", "al_spectral_mac", "al_block_synthesis", "al_event_stats"):
+        lib.call(name, ct.byref(desc), stream)
+    renderer.mem.synchronize()
+    stats = batch.bufs["event_stats"]
+    if isinstance(stats, np.ndarray):  # host-emulated memory (tests): go through torch CPU tensors
+        t = torch.from_numpy(stats).view(-1, 4)
+    else:
+        t = stats.view(-1, 4)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        sums = t[:, [0, 2]].contiguous()
+        peak = t[:, 1].contiguous()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        dist.all_reduce(peak, op=dist.ReduceOp.MAX)
+        t[:, 0], t[:, 2], t[:, 1] = sums[:, 0], sums[:, 1], peak
+    lib.call("al_event_levels_from_stats", ct.byref(desc), int(total_capsules), stream)
+    return batch.result()
+
+
+def _allreduce_emitter_gains(renderer, batch, total_capsules: int):
+    """g[n] = total_capsules / sum_c ||h_{n,c}|| with the norm sum all-reduced over ranks."""
+    import torch
+    import torch.distributed as dist
+
+    pl = batch.plan
+    renderer.mem.synchronize()
+    energy = renderer.mem.download(batch.bufs["ir_energy"])[: pl.hspec_blocks].astype(np.float64)
+    norms = np.sqrt(energy.reshape(pl.n_emitters, pl.n_capsules, pl.n_partitions).sum(axis=2)) + np.finfo(np.float64).tiny
+    total = torch.from_numpy(norms.sum(axis=1))
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            total = total.cuda()
+        dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        total = total.cpu()
+    g = (total_capsules / total.numpy()).astype(np.float32)
+    mem = renderer.mem
+    return mem.upload(g) if not isinstance(batch.bufs["emitter_gain"], np.ndarray) else g

@@ -149,6 +149,11 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 
 int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */
+/* The two halves of al_event_levels, for a scene whose capsules are sharded over several GPUs: every rank reduces
+ * its own capsules into event_stats[e] = {sum|x|, max|x|, non-finite count, -}, the ranks all-reduce those E triples
+ * (SUM, MAX, SUM), then every rank evaluates the level law with the TOTAL capsule count. */
+int al_event_stats(const al_batch *b, al_stream_t stream);
+int al_event_levels_from_stats(const al_batch *b, int32_t total_capsules, al_stream_t stream);
 int al_render_batch(const al_batch *b, al_stream_t stream);
 
 /* A11 mixdown and helpers. */

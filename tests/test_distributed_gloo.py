@@ -69,3 +69,54 @@ def test_shard_indices_cover_everything():
     for world in (1, 2, 3, 8):
         owned = sorted(i for r in range(world) for i in shard_indices(11, r, world))
         assert owned == list(range(11))
+
+
+CAPSULE_WORKER = textwrap.dedent("""
+    import sys
+    import numpy as np
+    sys.path.insert(0, {root!r})
+    from audiblelight_amd import _hip, distributed, engine, plan as planning
+    from tests import hostemu
+
+    rng = np.random.default_rng(7)
+    C, L, sr = 4, 400, 8000
+    specs, clips, irs, col = [], [], [], 0
+    for n, ne in ((1500, 1), (2100, 3), (900, 1)):
+        clips.append(rng.standard_normal(n).astype(np.float32))
+        irs.append(rng.standard_normal((C, ne, L)).astype(np.float32))
+        specs.append(planning.EventSpec(n_samples=n, n_emitters=ne, snr=float(rng.uniform(5, 30)), emitter0=col,
+                                        is_moving=ne > 1, duration=n / sr))
+        col += ne
+    mic_ir = np.concatenate(irs, axis=1)
+    r = engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
+    dist = distributed.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    rows = distributed.capsule_slice(C, rank, world)
+    res = distributed.render_capsule_sharded(r, specs, clips, mic_ir[rows], C, sr, log2_block=10)
+    full = r.render(planning.plan_batch(specs, C, L, sr, log2_block=10), clips, mic_ir)   # single-GPU reference
+    np.testing.assert_allclose(res.scales(), full.scales(), rtol=1e-6)
+    for i in range(len(specs)):
+        np.testing.assert_allclose(res.spatial_audio(i), full.spatial_audio(i)[rows], rtol=2e-5, atol=1e-9)
+    dist.destroy_process_group()
+    open({out!r} + str(rank), "w").write("ok")
+""")
+
+
+def test_two_rank_capsule_sharding(tmp_path):
+    from tests import hostemu
+
+    hostemu.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "done")
+    script = tmp_path / "worker_caps.py"
+    script.write_text(CAPSULE_WORKER.format(root=ROOT, out=out))
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\\n".join(logs)
+    assert os.path.exists(out + "0") and os.path.exists(out + "1")

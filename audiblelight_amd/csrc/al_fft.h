@@ -137,7 +137,9 @@ struct PassTwiddles {
   float2 a[NB], c[NB];
 };
 
-template <int LOG2M, int DIR, int PASS>
+// TWS = stride of this transform's factors inside the table (1: the table was made for this size, 2: the
+// table belongs to a transform twice as long, used by the split kernels).
+template <int LOG2M, int DIR, int PASS, int TWS = 1>
 __device__ __forceinline__ void load_pass_twiddles(PassTwiddles<LOG2M, PASS> &t, const float2 *__restrict__ tw, int tid) {
   constexpr int M = 1 << LOG2M, T = M / 16;
   constexpr int R = fft_radix(LOG2M, PASS);
@@ -147,8 +149,8 @@ __device__ __forceinline__ void load_pass_twiddles(PassTwiddles<LOG2M, PASS> &t,
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
     const int k = (tid + T * b) & (NS - 1);
-    t.a[b] = tw[k * STEP];
-    t.c[b] = (R > 4) ? tw[4 * k * STEP] : t.a[b];
+    t.a[b] = tw[TWS * k * STEP];
+    t.c[b] = (R > 4) ? tw[TWS * 4 * k * STEP] : t.a[b];
     if (DIR > 0) {
       t.a[b].y = -t.a[b].y;
       t.c[b].y = -t.c[b].y;
@@ -241,15 +243,15 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassT
   __syncthreads();
 }
 
-template <int LOG2M, int DIR, int PASS, bool LAST_REGS>
+template <int LOG2M, int DIR, int PASS, bool LAST_REGS, int TWS = 1>
 struct FftPasses {
   static __device__ __forceinline__ void run(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid,
                                              const PassTwiddles<LOG2M, PASS> &cur) {
     if constexpr (PASS + 1 < fft_npasses(LOG2M)) {
       PassTwiddles<LOG2M, PASS + 1> nxt;
-      load_pass_twiddles<LOG2M, DIR, PASS + 1>(nxt, tw, tid);  // in flight during this pass
+      load_pass_twiddles<LOG2M, DIR, PASS + 1, TWS>(nxt, tw, tid);  // in flight during this pass
       fft_pass<LOG2M, DIR, PASS>(v, s, cur, tid);
-      FftPasses<LOG2M, DIR, PASS + 1, LAST_REGS>::run(v, s, tw, tid, nxt);
+      FftPasses<LOG2M, DIR, PASS + 1, LAST_REGS, TWS>::run(v, s, tw, tid, nxt);
     } else {
       fft_pass<LOG2M, DIR, PASS, LAST_REGS>(v, s, cur, tid);
     }
@@ -268,10 +270,10 @@ __device__ __forceinline__ void fft_regs_to_lds(float2 (&v)[16], float2 *s, cons
 // has finished READING the LDS image when this returns to any thread past its next barrier; the image
 // may be overwritten after one __syncthreads() ... in fact the last pass already ends its reads with a
 // barrier, so the caller may write LDS immediately.
-template <int LOG2M, int DIR>
+template <int LOG2M, int DIR, int TWS = 1>
 __device__ __forceinline__ void fft_regs_to_regs(float2 (&v)[16], float2 *s, const float2 *__restrict__ tw, int tid) {
   PassTwiddles<LOG2M, 0> none;
-  FftPasses<LOG2M, DIR, 0, true>::run(v, s, tw, tid, none);
+  FftPasses<LOG2M, DIR, 0, true, TWS>::run(v, s, tw, tid, none);
 }
 
 // ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)
@@ -382,6 +384,104 @@ __device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ i
       const float2 o = cmul(cconj(w[m]), d);
       v[m] = make_float2(e.x - o.y, e.y + o.x);
       s[lds_pad(M - k)] = make_float2(e.x + o.y, o.x - e.y);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int m = 8; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
+  __syncthreads();
+}
+
+// ---- Split transforms: one block of M = 2^LOG2M complex points done as TWO transforms of M/2 points by a
+// workgroup of M/32 threads, in an LDS image of M/2 points.  Halving the image doubles the workgroups a CU
+// can hold (B = 8192: 4 x 35 KB instead of 2 x 70 KB), which is what hides HBM latency in these kernels.
+//   forward (decimation in frequency): Z[2k]   = FFT_{M/2}( z[n] + z[n+M/2] )[k]
+//                                      Z[2k+1] = FFT_{M/2}( (z[n] - z[n+M/2]) * w^n )[k],  w = exp(-2*pi*i/M)
+//   inverse (decimation in time):      z[n+M/2] = A[n] - conj(w)^n B[n],  A = IFFT_{M/2}(Z[2k]), B = IFFT_{M/2}(Z[2k+1])
+// Real packing works per half because bins pair up within a parity class: (2k, M-2k) and (2k+1, M-2k-1).
+// `tw` is the table of the FULL size: tw[j] = exp(-i*pi*j/M).
+//
+// Even half, forward: v[m] = Z[2k], k = tid + T*m (T = M/32).  Stores X[2k] and X[M-2k].
+template <int LOG2M>
+__device__ __forceinline__ void split_unpack_store_even(const float2 (&v)[16], float2 *s, const float2 *__restrict__ tw,
+                                                        int tid, float2 *__restrict__ out) {
+  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
+  float2 w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w[m] = tw[2 * (tid + T * m)];
+#pragma unroll
+  for (int m = 8; m < 16; ++m) s[lds_pad(tid + T * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (k == 0) {
+      const float2 z0 = v[0], zh = v[8];  // Z[0] and Z[M/2] = even-half element MH/2
+      out[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
+      out[M / 2] = cconj(zh);
+    } else {
+      const float2 zk = v[m], zm = s[lds_pad(MH - k)];
+      const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+      const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+      const float2 wo = cmul(w[m], make_float2(d.y, -d.x));
+      out[2 * k] = cadd(e, wo);
+      out[M - 2 * k] = cconj(csub(e, wo));
+    }
+  }
+  __syncthreads();
+}
+
+// Odd half, forward: v[m] = Z[2k+1].  Partner of bin 2k+1 is bin M-2k-1 = odd-half element MH-1-k.
+template <int LOG2M>
+__device__ __forceinline__ void split_unpack_store_odd(const float2 (&v)[16], float2 *s, const float2 *__restrict__ tw,
+                                                       int tid, float2 *__restrict__ out) {
+  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
+  float2 w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w[m] = tw[2 * (tid + T * m) + 1];
+#pragma unroll
+  for (int m = 8; m < 16; ++m) s[lds_pad(tid + T * m)] = v[m];
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    const float2 zk = v[m], zm = s[lds_pad(MH - 1 - k)];
+    const float2 e = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+    const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+    const float2 wo = cmul(w[m], make_float2(d.y, -d.x));
+    out[2 * k + 1] = cadd(e, wo);
+    out[M - 2 * k - 1] = cconj(csub(e, wo));
+  }
+  __syncthreads();
+}
+
+// Inverse, one parity class: builds the half-size transform input v[m] = Z[2k + ODD] (scaled) from the packed
+// spectrum `in` of the full block.
+template <int LOG2M, int ODD>
+__device__ __forceinline__ void split_pack_load(const float2 *__restrict__ in, float2 (&v)[16], float2 *s,
+                                                const float2 *__restrict__ tw, int tid, float scale) {
+  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
+  float2 yk[8], ym[8], w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int j = 2 * (tid + T * m) + ODD;
+    yk[m] = in[j];
+    ym[m] = in[j == 0 ? M / 2 : M - j];
+    w[m] = tw[j];
+  }
+  const float hs = 0.5f * scale;
+#pragma unroll
+  for (int m = 0; m < 8; ++m) {
+    const int k = tid + T * m;
+    if (ODD == 0 && k == 0) {
+      v[0] = make_float2(hs * (yk[0].x + yk[0].y), hs * (yk[0].x - yk[0].y));
+      s[lds_pad(MH / 2)] = make_float2(scale * ym[0].x, -scale * ym[0].y);
+    } else {
+      const float2 e = make_float2(hs * (yk[m].x + ym[m].x), hs * (yk[m].y - ym[m].y));
+      const float2 d = make_float2(hs * (yk[m].x - ym[m].x), hs * (yk[m].y + ym[m].y));
+      const float2 o = cmul(cconj(w[m]), d);
+      v[m] = make_float2(e.x - o.y, e.y + o.x);
+      s[lds_pad(MH - ODD - k)] = make_float2(e.x + o.y, o.x - e.y);  // Z[M - j] = element MH-k (even) / MH-1-k (odd)
     }
   }
   __syncthreads();

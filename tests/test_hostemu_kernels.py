@@ -43,6 +43,18 @@ def test_emu_static_event_matches_reference(emu, golden, log2_block):
     res.check_finite()
 
 
+def test_emu_split_transforms_forced_at_4096(emu, golden, monkeypatch):
+    """The split (two half-size transforms per workgroup) kernels, forced for B = 4096, incl. a moving event."""
+    monkeypatch.setenv("AL_SPLIT_FLAGS", "4")   # AL_FLAG_FORCE_SPLIT
+    a, h = golden["g1_audio"], golden["g1_irs"]
+    pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=10.0)], 4, h.shape[2], 8000, log2_block=12)
+    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1_spatial"]) < TOL
+    a, h = golden["g3b_audio"], golden["g3b_irs"]
+    spec = planning.EventSpec(n_samples=len(a), n_emitters=5, snr=12.0, is_moving=True, duration=len(a) / 8000)
+    pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=12)
+    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"]) < TOL
+
+
 @pytest.mark.parametrize("log2_block", [13, 14])
 def test_emu_large_blocks(emu, golden, log2_block):
     a, h = golden["g1b_audio"], golden["g1b_irs"]  # clip shorter than the IR

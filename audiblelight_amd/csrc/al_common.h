@@ -1,0 +1,54 @@
+// Pieces shared by the two translation units of the HIP extension (al_transforms.hip: FFT kernels, built
+// with -fno-slp-vectorize; al_kernels.hip: everything else + the C ABI, built with default vectorisation).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/audiblelight_hip.h"
+
+namespace al {
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
+template <int... Is, class F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// ------------------------------------------------------------------ block-wide reductions
+// sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
+__device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,
+                                              int nthreads) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a_sum += __shfl_down(a_sum, off, 64);
+    b_max = fmaxf(b_max, __shfl_down(b_max, off, 64));
+    c_sum += __shfl_down(c_sum, off, 64);
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) {
+    scratch[wave * 3 + 0] = a_sum;
+    scratch[wave * 3 + 1] = b_max;
+    scratch[wave * 3 + 2] = c_sum;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    const int nw = (nthreads + 63) >> 6;
+    for (int w = 1; w < nw; ++w) {
+      a_sum += scratch[w * 3 + 0];
+      b_max = fmaxf(b_max, scratch[w * 3 + 1]);
+      c_sum += scratch[w * 3 + 2];
+    }
+  }
+}
+
+// launchers of the transform kernels (defined in al_transforms.hip); return hipGetLastError() of the launch
+hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream);
+hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream);
+hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream);
+
+}  // namespace al

@@ -14,51 +14,12 @@
 #include <stdio.h>
 #include <string.h>
 
-#include <type_traits>
-#include <utility>
 
-#include "../../include/audiblelight_hip.h"
+#include "al_common.h"
 #include "al_fft.h"
 #include "al_bigfft.h"
 
 namespace al {
-
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
-template <int... Is, class F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-  (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) {
-  static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
-
-// ------------------------------------------------------------------ block-wide reductions
-// sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
-__device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,
-                                              int nthreads) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    a_sum += __shfl_down(a_sum, off, 64);
-    b_max = fmaxf(b_max, __shfl_down(b_max, off, 64));
-    c_sum += __shfl_down(c_sum, off, 64);
-  }
-  const int wave = tid >> 6, lane = tid & 63;
-  if (lane == 0) {
-    scratch[wave * 3 + 0] = a_sum;
-    scratch[wave * 3 + 1] = b_max;
-    scratch[wave * 3 + 2] = c_sum;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    const int nw = (nthreads + 63) >> 6;
-    for (int w = 1; w < nw; ++w) {
-      a_sum += scratch[w * 3 + 0];
-      b_max = fmaxf(b_max, scratch[w * 3 + 1]);
-      c_sum += scratch[w * 3 + 2];
-    }
-  }
-}
 
 // ------------------------------------------------------------------ twiddle table
 __global__ void k_twiddle_init(float2 *tw, int m) {
@@ -68,99 +29,6 @@ __global__ void k_twiddle_init(float2 *tw, int m) {
     sincospi(-(double)k / (double)m, &s, &c);
     tw[k] = make_float2((float)c, (float)s);
   }
-}
-
-// ------------------------------------------------------------------ 1. IR partition spectra
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_ir_spectra(al_batch b) {
-  constexpr int M = 1 << LOG2M, T = M / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M)];
-  __shared__ float red[48];
-  const int tid = threadIdx.x;
-  const int p = blockIdx.x, c = blockIdx.y, n = b.emitter0 + blockIdx.z;
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  const float *src = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)n * b.ir_stride_n + (int64_t)p * M;
-  const int remaining = b.ir_len - p * M;  // samples of this partition that exist (may exceed M)
-  float2 v[16];
-  float energy = 0.f;
-  // first half of the 2B window = the partition, second half zero.  Loads are unconditional
-  // (clamped addresses + selects) so all eight are in flight together.
-  if (remaining >= M) {  // workgroup-uniform
-#pragma unroll
-    for (int m = 0; m < 8; ++m) v[m] = *reinterpret_cast<const float2 *>(src + 2 * (tid + T * m));
-  } else {
-    const int last = remaining - 1;
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int t = 2 * (tid + T * m);
-      const float x0 = src[min(t, last)], x1 = src[min(t + 1, last)];
-      v[m] = make_float2(t <= last ? x0 : 0.f, t + 1 <= last ? x1 : 0.f);
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < 8; ++m) {
-    energy = fmaf(v[m].x, v[m].x, energy);
-    energy = fmaf(v[m].y, v[m].y, energy);
-  }
-#pragma unroll
-  for (int m = 8; m < 16; ++m) v[m] = make_float2(0.f, 0.f);
-
-  fft_regs_to_regs<LOG2M, -1>(v, s, tw, tid);
-  const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;  // global (energy partials)
-  const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;  // chunk-local spectrum
-  real_unpack_store_regs<LOG2M>(v, s, tw, tid, reinterpret_cast<float2 *>(b.hspec) + hblk * M);
-  __syncthreads();  // the reduction below reuses LDS-adjacent scratch only, but keep phases separate
-
-  float mx = 0.f, z = 0.f;
-  block_reduce3(energy, mx, z, red, tid, T);
-  if (tid == 0) b.ir_energy[blk] = energy;
-}
-
-// Split variant (see al_fft.h "Split transforms"): M/32 threads, two half-size transforms, half the LDS.
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M - 1)) void k_ir_spectra_split(al_batch b) {
-  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M - 1)];
-  __shared__ float red[48];
-  const int tid = threadIdx.x;
-  const int p = blockIdx.x, c = blockIdx.y, n = b.emitter0 + blockIdx.z;
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  const float *src = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)n * b.ir_stride_n + (int64_t)p * M;
-  const int remaining = b.ir_len - p * M;
-  // the partition fills complex points [0, MH) of the window, the upper half is zero: a[n] = z[n], b[n] = z[n] w^n
-  float2 z[16];
-  if (remaining >= M) {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) z[m] = *reinterpret_cast<const float2 *>(src + 2 * (tid + T * m));
-  } else {
-    const int last = remaining - 1;
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int t = 2 * (tid + T * m);
-      const float x0 = src[min(t, last)], x1 = src[min(t + 1, last)];
-      z[m] = make_float2(t <= last ? x0 : 0.f, t + 1 <= last ? x1 : 0.f);
-    }
-  }
-  float energy = 0.f;
-  float2 v[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    energy = fmaf(z[m].x, z[m].x, energy);
-    energy = fmaf(z[m].y, z[m].y, energy);
-    v[m] = z[m];
-  }
-  const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;
-  const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;
-  float2 *out = reinterpret_cast<float2 *>(b.hspec) + hblk * M;
-  fft_regs_to_regs<LOG2M - 1, -1, 2>(v, s, tw, tid);
-  split_unpack_store_even<LOG2M>(v, s, tw, tid, out);
-#pragma unroll
-  for (int m = 0; m < 16; ++m) v[m] = cmul(z[m], tw[2 * (tid + T * m)]);
-  fft_regs_to_regs<LOG2M - 1, -1, 2>(v, s, tw, tid);
-  split_unpack_store_odd<LOG2M>(v, s, tw, tid, out);
-  float mx = 0.f, zz = 0.f;
-  block_reduce3(energy, mx, zz, red, tid, T);
-  if (tid == 0) b.ir_energy[blk] = energy;
 }
 
 // ------------------------------------------------------------------ 2. emitter gains (normalize_irs)
@@ -177,109 +45,6 @@ __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)b.n_capsules / acc);
-}
-
-// ------------------------------------------------------------------ 3. signal block spectra
-// Cross-fade envelope of a moving stream at sample t:
-//   env(t) = W[q+1] * win(r) + W[q] * (1 - win(r)),  q = t / hop, r = t % hop, win(r) = sin^2(pi r / (2 hop))
-__device__ __forceinline__ float stream_envelope(const float *__restrict__ w, int w_len, int hop, int t) {
-  const int q = t / hop, r = t - q * hop;
-  const float sn = sinpif((float)r / (float)(2 * hop));
-  const float win = sn * sn;
-  const float a0 = w[min(q, w_len - 1)], a1 = w[min(q + 1, w_len - 1)];  // unconditional loads
-  const float w0 = q < w_len ? a0 : 0.f;
-  const float w1 = q + 1 < w_len ? a1 : 0.f;
-  return fmaf(w1 - w0, win, w0);
-}
-
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_signal_spectra(al_batch b) {
-  constexpr int M = 1 << LOG2M, T = M / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M)];
-  const int tid = threadIdx.x;
-  const al_stream st = b.streams[b.stream0 + blockIdx.y];
-  if ((int)blockIdx.x >= st.n_j) return;
-  const al_event ev = b.events[st.event];
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  const float *a = b.audio + ev.audio_off;
-  const bool moving = st.w_off >= 0 && st.w_len > 0;
-  const float *w = b.wtab + (moving ? st.w_off : 0);
-  const int j = st.j_lo + blockIdx.x;
-  const int t0 = (j - 1) * M;  // window [(j-1)B, (j+1)B)
-  const int last = ev.len - 1;
-  float2 v[16];
-  if (t0 >= 0 && t0 + 2 * M <= ev.len) {  // interior window (workgroup-uniform): aligned pair loads
-#pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = *reinterpret_cast<const float2 *>(a + t0 + 2 * (tid + T * m));
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int t = t0 + 2 * (tid + T * m);
-      const float x0 = a[min(max(t, 0), last)], x1 = a[min(max(t + 1, 0), last)];
-      v[m] = make_float2((t >= 0 && t <= last) ? x0 : 0.f, (t + 1 >= 0 && t + 1 <= last) ? x1 : 0.f);
-    }
-  }
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    const int t = t0 + 2 * (tid + T * m);
-    float g0 = st.gain, g1 = st.gain;
-    if (moving) {  // workgroup-uniform
-      g0 *= stream_envelope(w, st.w_len, b.hop, max(t, 0));
-      g1 *= stream_envelope(w, st.w_len, b.hop, max(t + 1, 0));
-    }
-    v[m].x *= g0;
-    v[m].y *= g1;
-  }
-  fft_regs_to_regs<LOG2M, -1>(v, s, tw, tid);
-  real_unpack_store_regs<LOG2M>(v, s, tw, tid, reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M);
-}
-
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M - 1)) void k_signal_spectra_split(al_batch b) {
-  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M - 1)];
-  const int tid = threadIdx.x;
-  const al_stream st = b.streams[b.stream0 + blockIdx.y];
-  if ((int)blockIdx.x >= st.n_j) return;
-  const al_event ev = b.events[st.event];
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  const float *a = b.audio + ev.audio_off;
-  const bool moving = st.w_off >= 0 && st.w_len > 0;
-  const float *w = b.wtab + (moving ? st.w_off : 0);
-  const int j = st.j_lo + blockIdx.x;
-  const int t0 = (j - 1) * M;  // window [(j-1)B, (j+1)B) = complex points [0, M)
-  const int last = ev.len - 1;
-  const bool interior = (t0 >= 0 && t0 + 2 * M <= ev.len);
-  float2 va[16], vb[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    float2 lo, hi;  // z[n] and z[n + MH]
-    const int tl = t0 + 2 * (tid + T * m), th = tl + M;
-    if (interior) {
-      lo = *reinterpret_cast<const float2 *>(a + tl);
-      hi = *reinterpret_cast<const float2 *>(a + th);
-    } else {
-      const float l0 = a[min(max(tl, 0), last)], l1 = a[min(max(tl + 1, 0), last)];
-      const float h0 = a[min(max(th, 0), last)], h1 = a[min(max(th + 1, 0), last)];
-      lo = make_float2((tl >= 0 && tl <= last) ? l0 : 0.f, (tl + 1 >= 0 && tl + 1 <= last) ? l1 : 0.f);
-      hi = make_float2((th >= 0 && th <= last) ? h0 : 0.f, (th + 1 >= 0 && th + 1 <= last) ? h1 : 0.f);
-    }
-    float gl0 = st.gain, gl1 = st.gain, gh0 = st.gain, gh1 = st.gain;
-    if (moving) {
-      gl0 *= stream_envelope(w, st.w_len, b.hop, max(tl, 0));
-      gl1 *= stream_envelope(w, st.w_len, b.hop, max(tl + 1, 0));
-      gh0 *= stream_envelope(w, st.w_len, b.hop, max(th, 0));
-      gh1 *= stream_envelope(w, st.w_len, b.hop, max(th + 1, 0));
-    }
-    lo.x *= gl0; lo.y *= gl1; hi.x *= gh0; hi.y *= gh1;
-    va[m] = cadd(lo, hi);
-    vb[m] = cmul(csub(lo, hi), tw[2 * (tid + T * m)]);
-  }
-  float2 *out = reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * M;
-  fft_regs_to_regs<LOG2M - 1, -1, 2>(va, s, tw, tid);
-  split_unpack_store_even<LOG2M>(va, s, tw, tid, out);
-  fft_regs_to_regs<LOG2M - 1, -1, 2>(vb, s, tw, tid);
-  split_unpack_store_odd<LOG2M>(vb, s, tw, tid, out);
 }
 
 // ------------------------------------------------------------------ 4. frequency-domain accumulate
@@ -394,159 +159,6 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
       if (k0 + kk < K) acc[kk].store(Y + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f);
-  }
-}
-
-// ------------------------------------------------------------------ 5. block synthesis
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_block_synthesis(al_batch b) {
-  constexpr int M = 1 << LOG2M, T = M / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M)];
-  __shared__ float red[48];
-  const int tid = threadIdx.x;
-  const int k = blockIdx.x, c = blockIdx.y;
-  const al_event ev = b.events[b.event0 + blockIdx.z];
-  if (k >= ev.n_blocks) return;
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  float *out = b.spatial + ev.out_off + (int64_t)c * ev.len;
-  const int tbase = k * M;
-  float asum = 0.f, amax = 0.f, bad = 0.f;
-
-  if (ev.n_streams <= 0) {
-    // no emitters: the clip is tiled over the capsules (synthesize.py:572-577)
-    const float gain = b.streams[ev.stream0].gain;
-    const float *a = b.audio + ev.audio_off;
-    for (int i = tid; i < M; i += T) {
-      const int t = tbase + i;
-      if (t < ev.len) {
-        const float x = a[t] * gain;
-        out[t] = x;
-        asum += fabsf(x);
-        amax = fmaxf(amax, fabsf(x));
-        bad += isfinite(x) ? 0.f : 1.f;
-      }
-    }
-  } else {
-    const float2 *y = reinterpret_cast<const float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks + k) * M;
-    float2 v[16];
-    real_pack_load_regs<LOG2M>(y, v, s, tw, tid, 1.0f / (float)M);
-    fft_regs_to_regs<LOG2M, 1>(v, s, tw, tid);
-    // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B); those are
-    // this thread's registers v[8..15] (n = tid + T*m), so the result never goes back through LDS
-    const bool pair_ok = (((ev.out_off + (int64_t)c * ev.len) & 1) == 0);
-#pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int i = tid + T * m;  // complex index inside the kept half
-      const float2 z = v[8 + m];
-      const int t = tbase + 2 * i;
-      const float x0 = t < ev.valid_len ? z.x : 0.f;
-      const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
-      if (t + 1 < ev.len) {
-        if (pair_ok) {
-          *reinterpret_cast<float2 *>(out + t) = make_float2(x0, x1);
-        } else {
-          out[t] = x0;
-          out[t + 1] = x1;
-        }
-      } else if (t < ev.len) {
-        out[t] = x0;
-      }
-      if (t < ev.len) {
-        asum += fabsf(x0);
-        amax = fmaxf(amax, fabsf(x0));
-        bad += isfinite(x0) ? 0.f : 1.f;
-      }
-      if (t + 1 < ev.len) {
-        asum += fabsf(x1);
-        amax = fmaxf(amax, fabsf(x1));
-        bad += isfinite(x1) ? 0.f : 1.f;
-      }
-    }
-  }
-  block_reduce3(asum, amax, bad, red, tid, T);
-  if (tid == 0) {
-    float *pp = b.partials + 4 * ((int64_t)ev.part_base + (int64_t)c * ev.n_blocks + k);
-    pp[0] = asum;
-    pp[1] = amax;
-    pp[2] = bad;
-    pp[3] = 0.f;
-  }
-}
-
-template <int LOG2M>
-__global__ __launch_bounds__(fft_threads(LOG2M - 1)) void k_block_synthesis_split(al_batch b) {
-  constexpr int M = 1 << LOG2M, MH = M / 2, T = MH / 16;
-  __shared__ float2 s[fft_lds_elems(LOG2M - 1)];
-  __shared__ float red[48];
-  const int tid = threadIdx.x;
-  const int k = blockIdx.x, c = blockIdx.y;
-  const al_event ev = b.events[b.event0 + blockIdx.z];
-  if (k >= ev.n_blocks) return;
-  const float2 *tw = reinterpret_cast<const float2 *>(b.twiddle);
-  float *out = b.spatial + ev.out_off + (int64_t)c * ev.len;
-  const int tbase = k * M;
-  float asum = 0.f, amax = 0.f, bad = 0.f;
-  if (ev.n_streams <= 0) {
-    const float gain = b.streams[ev.stream0].gain;
-    const float *a = b.audio + ev.audio_off;
-    for (int i = tid; i < M; i += T) {
-      const int t = tbase + i;
-      if (t < ev.len) {
-        const float x = a[t] * gain;
-        out[t] = x;
-        asum += fabsf(x);
-        amax = fmaxf(amax, fabsf(x));
-        bad += isfinite(x) ? 0.f : 1.f;
-      }
-    }
-  } else {
-    const float2 *y = reinterpret_cast<const float2 *>(b.yspec) +
-                      ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks + k) * M;
-    const float scale = 1.0f / (float)M;
-    float2 va[16], vb[16];
-    split_pack_load<LOG2M, 0>(y, va, s, tw, tid, scale);
-    fft_regs_to_regs<LOG2M - 1, 1, 2>(va, s, tw, tid);
-    __syncthreads();
-    split_pack_load<LOG2M, 1>(y, vb, s, tw, tid, scale);
-    fft_regs_to_regs<LOG2M - 1, 1, 2>(vb, s, tw, tid);
-    // the alias-free half of the window: z[n + M/2] = A[n] - conj(w)^n B[n], n = tid + T*m  ->  samples kB + 2n
-    const bool pair_ok = (((ev.out_off + (int64_t)c * ev.len) & 1) == 0);
-    const bool interior = pair_ok && (tbase + M <= ev.valid_len);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int n = tid + T * m;
-      const float2 z = csub(va[m], cmul(cconj(tw[2 * n]), vb[m]));
-      const int t = tbase + 2 * n;
-      if (interior) {
-        *reinterpret_cast<float2 *>(out + t) = z;
-        asum += fabsf(z.x) + fabsf(z.y);
-        amax = fmaxf(amax, fmaxf(fabsf(z.x), fabsf(z.y)));
-        bad += (isfinite(z.x) ? 0.f : 1.f) + (isfinite(z.y) ? 0.f : 1.f);
-      } else {
-        const float x0 = t < ev.valid_len ? z.x : 0.f;
-        const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
-        if (t < ev.len) {
-          out[t] = x0;
-          asum += fabsf(x0);
-          amax = fmaxf(amax, fabsf(x0));
-          bad += isfinite(x0) ? 0.f : 1.f;
-        }
-        if (t + 1 < ev.len) {
-          out[t + 1] = x1;
-          asum += fabsf(x1);
-          amax = fmaxf(amax, fabsf(x1));
-          bad += isfinite(x1) ? 0.f : 1.f;
-        }
-      }
-    }
-  }
-  block_reduce3(asum, amax, bad, red, tid, T);
-  if (tid == 0) {
-    float *pp = b.partials + 4 * ((int64_t)ev.part_base + (int64_t)c * ev.n_blocks + k);
-    pp[0] = asum;
-    pp[1] = amax;
-    pp[2] = bad;
-    pp[3] = 0.f;
   }
 }
 
@@ -864,14 +476,15 @@ int fail(int code, const char *msg) {
   return code;
 }
 
-int check_launch(const char *what) {
-  hipError_t e = hipGetLastError();
+int check_error(hipError_t e, const char *what) {
   if (e != hipSuccess) {
     snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
     return AL_E_HIP;
   }
   return AL_OK;
 }
+
+int check_launch(const char *what) { return check_error(hipGetLastError(), what); }
 
 int check_batch(const al_batch *b) {
   if (!b) return fail(AL_E_BADARG, "null batch");
@@ -886,30 +499,6 @@ int check_batch(const al_batch *b) {
   return AL_OK;
 }
 
-#define AL_DISPATCH_LOG2(log2, CALL)            \
-  switch (log2) {                               \
-    case 10: { constexpr int L = 10; CALL; } break; \
-    case 11: { constexpr int L = 11; CALL; } break; \
-    case 12: { constexpr int L = 12; CALL; } break; \
-    case 13: { constexpr int L = 13; CALL; } break; \
-    case 14: { constexpr int L = 14; CALL; } break; \
-    default: return fail(AL_E_UNSUPPORTED, "unsupported block size"); \
-  }
-// Blocks of 8192 and 16384 points use the split transforms (half the LDS image => twice the resident workgroups);
-// AL_FLAG_NO_SPLIT / AL_FLAG_FORCE_SPLIT override the choice (measurement knobs).
-#define AL_DISPATCH_SPLIT(log2, CALL)           \
-  switch (log2) {                               \
-    case 12: { constexpr int L = 12; CALL; } break; \
-    case 13: { constexpr int L = 13; CALL; } break; \
-    case 14: { constexpr int L = 14; CALL; } break; \
-    default: return fail(AL_E_UNSUPPORTED, "split transforms need log2_block in [12, 14]"); \
-  }
-
-bool use_split(const al_batch *b) {
-  if (b->flags & AL_FLAG_NO_SPLIT) return false;
-  if (b->flags & AL_FLAG_FORCE_SPLIT) return b->log2_block >= 12;
-  return b->log2_block >= 13;
-}
 }  // namespace
 
 extern "C" {
@@ -933,15 +522,7 @@ int al_twiddle_init(float *twiddle, int log2_block, al_stream_t stream) {
 int al_ir_spectra(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_emitters <= 0) return AL_OK;
-  const dim3 grid(b->n_partitions, b->n_capsules, b->n_emitters);
-  if (use_split(b)) {
-    AL_DISPATCH_SPLIT(b->log2_block, hipLaunchKernelGGL((al::k_ir_spectra_split<L>), grid, dim3(al::fft_threads(L - 1)), 0,
-                                                         (hipStream_t)stream, *b));
-  } else {
-    AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_ir_spectra<L>), grid, dim3(al::fft_threads(L)), 0,
-                                                        (hipStream_t)stream, *b));
-  }
-  return check_launch("k_ir_spectra");
+  return check_error(al::launch_ir_spectra(b, (hipStream_t)stream), "k_ir_spectra");
 }
 
 int al_emitter_gains(const al_batch *b, al_stream_t stream) {
@@ -954,15 +535,7 @@ int al_emitter_gains(const al_batch *b, al_stream_t stream) {
 int al_signal_spectra(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_streams <= 0 || b->max_nj <= 0) return AL_OK;
-  const dim3 grid(b->max_nj, b->n_streams);
-  if (use_split(b)) {
-    AL_DISPATCH_SPLIT(b->log2_block, hipLaunchKernelGGL((al::k_signal_spectra_split<L>), grid, dim3(al::fft_threads(L - 1)),
-                                                         0, (hipStream_t)stream, *b));
-  } else {
-    AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_signal_spectra<L>), grid, dim3(al::fft_threads(L)), 0,
-                                                        (hipStream_t)stream, *b));
-  }
-  return check_launch("k_signal_spectra");
+  return check_error(al::launch_signal_spectra(b, (hipStream_t)stream), "k_signal_spectra");
 }
 
 int al_spectral_mac(const al_batch *b, al_stream_t stream) {
@@ -993,15 +566,7 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
 int al_block_synthesis(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->max_blocks <= 0) return AL_OK;
-  const dim3 grid(b->max_blocks, b->n_capsules, b->n_events);
-  if (use_split(b)) {
-    AL_DISPATCH_SPLIT(b->log2_block, hipLaunchKernelGGL((al::k_block_synthesis_split<L>), grid, dim3(al::fft_threads(L - 1)),
-                                                         0, (hipStream_t)stream, *b));
-  } else {
-    AL_DISPATCH_LOG2(b->log2_block, hipLaunchKernelGGL((al::k_block_synthesis<L>), grid, dim3(al::fft_threads(L)), 0,
-                                                        (hipStream_t)stream, *b));
-  }
-  return check_launch("k_block_synthesis");
+  return check_error(al::launch_block_synthesis(b, (hipStream_t)stream), "k_block_synthesis");
 }
 
 int al_event_levels(const al_batch *b, al_stream_t stream) {

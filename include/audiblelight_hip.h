@@ -33,8 +33,8 @@ extern "C" {
 #define AL_FLAG_NO_IR_NORM 1 /* IRs are already normalised: emitter_gain := 1 (time_invariant_convolution,
                                  time_variant_convolution called directly, synthesize.py:71,277) */
 
-#define AL_FLAG_NO_SPLIT 2     /* measurement knob: one full-size transform per workgroup even for B >= 8192 */
-#define AL_FLAG_FORCE_SPLIT 4  /* measurement knob: split transforms also for B = 4096 */
+#define AL_FLAG_FORCE_SPLIT 4  /* opt-in: one block as two half-size transforms per workgroup (B >= 4096); slower on
+                                 MI355X (profiles/r01_split_transforms.txt), kept for boxes with less LDS headroom */
 
 #define AL_MIN_LOG2_BLOCK 10
 #define AL_MAX_LOG2_BLOCK 14

@@ -8,16 +8,17 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "_build", "libal_hostemu.so")
-SRC = os.path.join(ROOT, "audiblelight_amd", "csrc", "al_kernels.hip")
+CSRC = os.path.join(ROOT, "audiblelight_amd", "csrc")
+SRCS = [os.path.join(CSRC, "al_kernels.hip"), os.path.join(CSRC, "al_transforms.hip")]
 
 
 def build(sanitize: bool = False) -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    deps = [SRC, os.path.join(ROOT, "audiblelight_amd", "csrc", "al_fft.h"),
-            os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
+    deps = SRCS + [os.path.join(CSRC, f) for f in ("al_fft.h", "al_bigfft.h", "al_common.h")] + [
+        os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):
         return LIB
-    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", HERE, SRC, "-o", LIB]
+    cmd = ["g++", "-std=c++17", "-O2", "-g", "-fPIC", "-shared", "-pthread", "-x", "c++", "-I", HERE] + SRCS + ["-o", LIB]
     if sanitize:
         cmd[3:3] = ["-fsanitize=address,undefined"]
     subprocess.check_call(cmd)

@@ -34,6 +34,7 @@ static inline float4 make_float4(float x, float y, float z, float w) { return fl
 typedef void *hipStream_t;
 typedef int hipError_t;
 static const hipError_t hipSuccess = 0;
+static const hipError_t hipErrorInvalidValue = 1;
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline const char *hipGetErrorString(hipError_t) { return "hostemu"; }
 

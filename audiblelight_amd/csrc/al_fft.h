@@ -170,9 +170,11 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassT
   constexpr int R = fft_radix(LOG2M, PASS);
   constexpr int NS = 1 << (4 * PASS);
   constexpr int NB = 16 / R;
+  static_assert(T % 16 == 0, "lds_pad(a + c) == lds_pad(a) + lds_pad(c) needs c % 16 == 0");
   if (PASS > 0) {
+    const float2 *rd = s + lds_pad(tid);  // slot m lives at rd[lds_pad(T*m)]: one base register, immediate offsets
 #pragma unroll
-    for (int m = 0; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
+    for (int m = 0; m < 16; ++m) v[m] = rd[lds_pad(T * m)];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float2 w[16];
@@ -215,29 +217,33 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[16], float2 *s, const PassT
     const int j = tid + T * b;
     const int k = j & (NS - 1);
     const int base = (j - k) * R + k;
+    // output q goes to base + q*NS.  NS == 1 (first pass, R == 16): lds_pad(16 j + q) = 17 j + q.
+    // NS >= 16: q*NS is a multiple of 16, so lds_pad splits into a per-thread base and a constant offset.
+    float2 *wr = s + (NS == 1 ? 17 * j : lds_pad(base));
+    constexpr int QS = (NS == 1) ? 1 : lds_pad(NS);  // NS >= 16: lds_pad(q*NS) == q * lds_pad(NS)
     if (R == 16) {
       bfly16<DIR>(v);
 #pragma unroll
-      for (int q = 0; q < 16; ++q) s[lds_pad(base + q * NS)] = v[4 * (q & 3) + (q >> 2)];
+      for (int q = 0; q < 16; ++q) wr[q * QS] = v[4 * (q & 3) + (q >> 2)];
     } else if (R == 8) {
       float2 x[8];
 #pragma unroll
       for (int r = 0; r < 8; ++r) x[r] = v[b + r * NB];
       bfly8<DIR>(x);
 #pragma unroll
-      for (int q = 0; q < 8; ++q) s[lds_pad(base + q * NS)] = x[q];
+      for (int q = 0; q < 8; ++q) wr[q * QS] = x[q];
     } else if (R == 4) {
       float2 x0 = v[b], x1 = v[b + NB], x2 = v[b + 2 * NB], x3 = v[b + 3 * NB];
       bfly4<DIR>(x0, x1, x2, x3);
-      s[lds_pad(base)] = x0;
-      s[lds_pad(base + NS)] = x1;
-      s[lds_pad(base + 2 * NS)] = x2;
-      s[lds_pad(base + 3 * NS)] = x3;
+      wr[0] = x0;
+      wr[QS] = x1;
+      wr[2 * QS] = x2;
+      wr[3 * QS] = x3;
     } else {
       float2 x0 = v[b], x1 = v[b + NB];
       bfly2<DIR>(x0, x1);
-      s[lds_pad(base)] = x0;
-      s[lds_pad(base + NS)] = x1;
+      wr[0] = x0;
+      wr[QS] = x1;
     }
   }
   __syncthreads();
@@ -337,13 +343,14 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[16], fl
   float2 w[8];
 #pragma unroll
   for (int m = 0; m < 8; ++m) w[m] = tw[tid + T * m];  // issued before the exchange
+  float2 *own = s + lds_pad(tid);
 #pragma unroll
-  for (int m = 8; m < 16; ++m) s[lds_pad(tid + T * m)] = v[m];
+  for (int m = 8; m < 16; ++m) own[lds_pad(T * m)] = v[m];
   __syncthreads();
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
     const int k = tid + T * m;
-    if (k == 0) {
+    if (m == 0 && k == 0) {
       const float2 z0 = v[0], zh = v[8];  // thread 0 owns Z[0] and Z[M/2]
       out[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
       out[M / 2] = cconj(zh);

@@ -243,34 +243,38 @@ __global__ __launch_bounds__(fft_threads(LOG2M), 4) void k_block_synthesis(al_ba
     // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B); those are
     // this thread's registers v[8..15] (n = tid + T*m), so the result never goes back through LDS
     const bool pair_ok = (((ev.out_off + (int64_t)c * ev.len) & 1) == 0);
+    if (pair_ok && tbase + M <= ev.valid_len) {  // interior block (workgroup-uniform): unconditional pair stores
+      float *o = out + tbase + 2 * tid;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int i = tid + T * m;  // complex index inside the kept half
-      const float2 z = v[8 + m];
-      const int t = tbase + 2 * i;
-      const float x0 = t < ev.valid_len ? z.x : 0.f;
-      const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
-      if (t + 1 < ev.len) {
-        if (pair_ok) {
-          *reinterpret_cast<float2 *>(out + t) = make_float2(x0, x1);
-        } else {
+      for (int m = 0; m < 8; ++m) {
+        const float2 z = v[8 + m];
+        *reinterpret_cast<float2 *>(o + 2 * T * m) = z;
+        asum += fabsf(z.x) + fabsf(z.y);
+        amax = fmaxf(amax, fmaxf(fabsf(z.x), fabsf(z.y)));
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int i = tid + T * m;  // complex index inside the kept half
+        const float2 z = v[8 + m];
+        const int t = tbase + 2 * i;
+        const float x0 = t < ev.valid_len ? z.x : 0.f;
+        const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
+        if (t < ev.len) {
           out[t] = x0;
-          out[t + 1] = x1;
+          asum += fabsf(x0);
+          amax = fmaxf(amax, fabsf(x0));
         }
-      } else if (t < ev.len) {
-        out[t] = x0;
-      }
-      if (t < ev.len) {
-        asum += fabsf(x0);
-        amax = fmaxf(amax, fabsf(x0));
-        bad += isfinite(x0) ? 0.f : 1.f;
-      }
-      if (t + 1 < ev.len) {
-        asum += fabsf(x1);
-        amax = fmaxf(amax, fabsf(x1));
-        bad += isfinite(x1) ? 0.f : 1.f;
+        if (t + 1 < ev.len) {
+          out[t + 1] = x1;
+          asum += fabsf(x1);
+          amax = fmaxf(amax, fabsf(x1));
+        }
       }
     }
+    // a NaN or Inf anywhere makes the sum of magnitudes non-finite: one test per thread instead of one per sample
+    bad = isfinite(asum) ? 0.f : 1.f;
+    if (bad != 0.f) { asum = 0.f; amax = 0.f; }
   }
   block_reduce3(asum, amax, bad, red, tid, T);
   if (tid == 0) {

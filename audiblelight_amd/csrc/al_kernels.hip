@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   const int c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
+  if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
@@ -160,6 +161,80 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
     for (int kk = 0; kk < KT; ++kk)
       if (k0 + kk < K) acc[kk].store(Y + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f);
   }
+}
+
+// ------------------------------------------------------------------ 4b. accumulate for moving events
+// A moving event is N streams (one per IR) whose clips are only a few blocks long (the cross-fade window of
+// that IR) and whose first blocks j_lo are non-decreasing.  One thread owns one bin (pair) of one capsule and
+// walks the streams in order with a SLIDING window of W = NJW + PT - 1 output accumulators anchored at the
+// current stream's j_lo: blocks that fall behind the window are complete and are written out once.  Every H,
+// X and Y value moves exactly once and every register index is static.
+template <int NJW, int PT, int VB>
+__global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
+  using V = BinVec<VB>;
+  constexpr int W = NJW + PT - 1;
+  const int M = 1 << b.log2_block;
+  const int f = (blockIdx.x * 256 + threadIdx.x) * VB;
+  const int c = blockIdx.y;
+  const al_event ev = b.events[b.event0 + blockIdx.z];
+  if (ev.n_streams <= 1 || ev.reserved != 1) return;  // static / dense events: k_spectral_mac
+  __shared__ int4 tab[64];    // {j_lo, n_j, emitter - emitter0, xspec_base - xspec_block0}
+  __shared__ float gains[64];
+  const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
+  const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
+  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks) * M + f;
+  const int K = ev.n_blocks, P = b.n_partitions;
+  const bool packed = (f == 0);
+  V acc[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) acc[w] = V::zero();
+  int kbase = 0;  // output block held in acc[0]
+  for (int l0 = 0; l0 < ev.n_streams; l0 += 64) {
+    __syncthreads();
+    if (threadIdx.x < 64 && l0 + (int)threadIdx.x < ev.n_streams) {
+      const al_stream st = b.streams[ev.stream0 + l0 + threadIdx.x];
+      tab[threadIdx.x] = make_int4(st.j_lo, st.n_j, st.emitter - b.emitter0, st.xspec_base - b.xspec_block0);
+      gains[threadIdx.x] = b.emitter_gain[st.emitter];
+    }
+    __syncthreads();
+    const int nl = min(64, ev.n_streams - l0);
+    for (int l = 0; l < nl; ++l) {
+      const int4 t = tab[l];
+      const int jlo = t.x, nj = t.y;
+      if (nj <= 0) continue;
+      // retire the blocks before this stream's first block
+      while (kbase < jlo) {
+        if (kbase < K) acc[0].store(Y + (int64_t)kbase * M);
+#pragma unroll
+        for (int w = 0; w + 1 < W; ++w) acc[w] = acc[w + 1];
+        acc[W - 1] = V::zero();
+        ++kbase;
+      }
+      const float g = gains[l];
+      const float2 *hp = H + (((int64_t)t.z * b.n_capsules + c) * P) * M + f;
+      const float2 *xp = X + (int64_t)t.w * M + f;
+      V h[PT], x[NJW];
+#pragma unroll
+      for (int pp = 0; pp < PT; ++pp) {
+        h[pp] = V::load(hp + (int64_t)min(pp, P - 1) * M);
+        h[pp].scale(pp < P ? g : 0.f);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NJW; ++jj) {
+        x[jj] = V::load(xp + (int64_t)min(jj, nj - 1) * M);
+        x[jj].scale(jj < nj ? 1.f : 0.f);
+      }
+#pragma unroll
+      for (int jj = 0; jj < NJW; ++jj)
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) acc[jj + pp].fma(x[jj], h[pp], packed);
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < W; ++w)
+    if (kbase + w < K) acc[w].store(Y + (int64_t)(kbase + w) * M);
+  // blocks beyond the last window (no stream reaches them) are zero
+  for (int k = kbase + W; k < K; ++k) V::zero().store(Y + (int64_t)k * M);
 }
 
 // ------------------------------------------------------------------ 6. event levels
@@ -560,6 +635,17 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   else if (wide_p) AL_MAC(8, 12, 1);
   else AL_MAC(8, 4, 1);
 #undef AL_MAC
+  if (int rc = check_launch("k_spectral_mac")) return rc;
+  // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
+  if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS) {
+    const dim3 grid(bins / 256, b->n_capsules, b->n_events);
+    if (b->n_partitions <= 12)
+      hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, 12, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+    else
+      hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, AL_SPARSE_MAX_PARTITIONS, 1>), grid, dim3(256), 0,
+                         (hipStream_t)stream, *b);
+    return check_launch("k_spectral_mac_moving");
+  }
   return check_launch("k_spectral_mac");
 }
 

@@ -16,6 +16,9 @@ from . import config
 from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
 
 
+SPARSE_MAX_NJ = 4  # AL_SPARSE_MAX_NJ of include/audiblelight_hip.h
+
+
 def _round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -190,6 +193,7 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
             n_frames = min(stft_frame_count(sp.stft_len or La, hop), w.shape[0])
             valid = min(La, max(n_frames * hop - win, 0))
             ev["n_streams"] = sp.n_emitters
+            first_stream = len(streams)
             for l in range(sp.n_emitters):
                 col = w[:n_frames, l]
                 nz = np.flatnonzero(col)
@@ -205,6 +209,10 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
                 x_blocks += n_j
                 wcols.append(col.astype(np.float32))
                 w_floats += n_frames
+            mine = streams[first_stream:]
+            starts_ok = all(a[2] <= b_[2] for a, b_ in zip(mine, mine[1:]) if a[3] > 0 and b_[3] > 0)
+            if starts_ok and max(st_[3] for st_ in mine) <= SPARSE_MAX_NJ:
+                ev["reserved"] = 1  # sliding-window accumulate (k_spectral_mac_moving)
         ev["valid_len"] = valid
         n_emit_used = max(n_emit_used, sp.emitter0 + sp.n_emitters)
         y_blocks += n_capsules * K if sp.n_emitters else 0

@@ -36,6 +36,9 @@ extern "C" {
 #define AL_FLAG_FORCE_SPLIT 4  /* opt-in: one block as two half-size transforms per workgroup (B >= 4096); slower on
                                  MI355X (profiles/r01_split_transforms.txt), kept for boxes with less LDS headroom */
 
+#define AL_SPARSE_MAX_NJ 4          /* longest stream (in blocks) the sliding-window accumulate accepts */
+#define AL_SPARSE_MAX_PARTITIONS 24 /* most IR partitions it accepts */
+
 #define AL_MIN_LOG2_BLOCK 10
 #define AL_MAX_LOG2_BLOCK 14
 
@@ -55,7 +58,7 @@ typedef struct {
   int32_t part_base;  /* index of (c=0,k=0) inside the partial-statistics array; layout [c][k] */
   float snr;          /* Event.snr */
   float ref_db;       /* Scene.ref_db (synthesize.py:598) */
-  int32_t reserved;
+  int32_t reserved;   /* 1: moving event whose streams all have n_j <= AL_SPARSE_MAX_NJ (sliding-window accumulate) */
 } al_event;
 
 /* One (event, emitter) source stream: the clip weighted by that emitter's cross-fade envelope

@@ -83,6 +83,26 @@ def test_emu_moving_event(emu, golden, tag, n_ir):
     assert rel_rms(res.spatial_audio(0), golden[f"{tag}_spatial"]) < TOL
 
 
+def test_emu_moving_event_sliding_window_kernel(emu, golden):
+    """Short streams (n_j <= 4 blocks) take k_spectral_mac_moving; result must match the reference as well."""
+    a, h = golden["g3b_audio"], golden["g3b_irs"]
+    spec = planning.EventSpec(n_samples=len(a), n_emitters=5, snr=12.0, is_moving=True, duration=len(a) / 8000)
+    pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=12)
+    assert pl.events["reserved"][0] == 1 and int(pl.streams["n_j"].max()) <= 4
+    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"]) < TOL
+    # and next to a static event + a long-stream moving event in the same batch (both kernels run)
+    a2, h2 = golden["g1_audio"], golden["g1_irs"]
+    a3, h3 = golden["g3a_audio"], golden["g3a_irs"][:, :, :1200]
+    specs = [planning.EventSpec(len(a2), 1, 10.0, emitter0=0), spec.__class__(len(a), 5, 12.0, emitter0=1, is_moving=True,
+                                                                                 duration=len(a) / 8000)]
+    irs = np.concatenate([h2[:, :, :1200], h], axis=1)
+    pl2 = planning.plan_batch(specs, 4, 1200, 8000, log2_block=12)
+    res = emu.render(pl2, [a2, a], irs)
+    assert rel_rms(res.spatial_audio(1), golden["g3b_spatial"]) < TOL
+    want = orc.render_event(a2, irs[:, :1, :].astype(np.float64), 10.0, sr=8000)["spatial"]
+    assert rel_rms(res.spatial_audio(0), want) < TOL
+
+
 def test_emu_full_scene_with_ambience(emu, golden):
     sr, dur, C = 8000, 2.0, 4
     specs, clips, irs, col = [], [], [], 0

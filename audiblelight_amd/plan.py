@@ -16,7 +16,7 @@ from . import config
 from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
 
 
-SPARSE_MAX_NJ = 4  # AL_SPARSE_MAX_NJ of include/audiblelight_hip.h
+SPARSE_MAX_NJ = 6  # AL_SPARSE_MAX_NJ of include/audiblelight_hip.h
 
 
 def _round_up(x: int, m: int) -> int:

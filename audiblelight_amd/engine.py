@@ -118,10 +118,12 @@ class Renderer:
         return host
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-                chunk_events: Optional[int] = None, normalize_irs: bool = True) -> "PreparedBatch":
+                chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
-        ``chunk_events``: run the batch as chunks of that many events over one reused spectra workspace."""
+        ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
+        ``lanes``: number of workspaces / HIP streams the chunks alternate over (chunk i runs on lane i % lanes),
+        so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another."""
         mem = self.mem
         if isinstance(irs, np.ndarray):
             irs, ir_strides = self.upload_irs(irs)
@@ -131,6 +133,7 @@ class Renderer:
         h_blocks = max(max(c["n_emitters"] for c in chunks) * C * P, 1)
         x_blocks = max(max(c["xspec_blocks"] for c in chunks), 1)
         y_blocks = max(max(c["yspec_blocks"] for c in chunks), 1)
+        lanes = max(1, min(int(lanes), len(chunks)))
         bufs = dict(
             audio=mem.upload(self.pack_audio(plan, clips)), ir=irs, events=mem.upload(plan.events),
             streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
@@ -141,14 +144,18 @@ class Renderer:
             partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
             event_scale=mem.empty(len(plan.events)))
         ptrs = {k: mem.ptr(v) for k, v in bufs.items()}
+        extra = [dict(hspec=mem.empty(h_blocks * B * 2), xspec=mem.empty(x_blocks * B * 2), yspec=mem.empty(y_blocks * B * 2))
+                 for _ in range(lanes - 1)]
+        lane_ptrs = [ptrs] + [dict(ptrs, **{k: mem.ptr(v) for k, v in e.items()}) for e in extra]
+        bufs["_lanes"] = extra
         descs = [_hip.AlBatch(
             log2_block=plan.log2_block, n_capsules=C, n_events=c["n_events"], n_streams=c["n_streams"],
             n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
             n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
-            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | (int(os.environ.get("AL_MAC_VARIANT", "0")) << 8) | int(os.environ.get("AL_SPLIT_FLAGS", "0")), **ptrs)
-            for c in chunks]
-        return PreparedBatch(self, plan, bufs, descs)
+            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | (int(os.environ.get("AL_MAC_VARIANT", "0")) << 8) | int(os.environ.get("AL_SPLIT_FLAGS", "0")), **lane_ptrs[i % lanes])
+            for i, c in enumerate(chunks)]
+        return PreparedBatch(self, plan, bufs, descs, lanes)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None,
@@ -193,10 +200,28 @@ class PreparedBatch:
     STAGES = ("al_ir_spectra", "al_emitter_gains", "al_signal_spectra", "al_spectral_mac", "al_block_synthesis",
               "al_event_levels")
 
-    def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, descs: List[_hip.AlBatch]):
-        self.renderer, self.plan, self.bufs, self.descs = renderer, plan, bufs, descs
+    def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, descs: List[_hip.AlBatch], lanes: int = 1):
+        self.renderer, self.plan, self.bufs, self.descs, self.lanes = renderer, plan, bufs, descs, lanes
+        self._streams = None
+
+    def _run_lanes(self) -> RenderResult:
+        """Chunk i on HIP stream i % lanes (torch streams); joins back into the current stream."""
+        torch = self.renderer.mem.torch
+        lib = self.renderer.lib
+        if self._streams is None:
+            self._streams = [torch.cuda.Stream(device=self.renderer.mem.device) for _ in range(self.lanes)]
+        cur = torch.cuda.current_stream(self.renderer.mem.device)
+        for st in self._streams:
+            st.wait_stream(cur)
+        for i, desc in enumerate(self.descs):
+            lib.call("al_render_batch", ct.byref(desc), ct.c_void_p(self._streams[i % self.lanes].cuda_stream))
+        for st in self._streams:
+            cur.wait_stream(st)
+        return self.result()
 
     def run(self, stages: Optional[Sequence[str]] = None) -> RenderResult:
+        if self.lanes > 1 and stages is None and hasattr(self.renderer.mem, "torch"):
+            return self._run_lanes()
         lib, stream = self.renderer.lib, self.renderer.mem.stream()
         for desc in self.descs:
             if stages is None:

@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
+    ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
     ap.add_argument("--cpu-events", type=int, default=6, help="events timed for the CPU baseline (0 = skip)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
     args = ap.parse_args()
@@ -94,7 +95,7 @@ def main():
     scene = synthetic.make_scene(args.config, scene_index=rank, scale=args.scale)
     r = engine.Renderer()
     pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
-    batch = r.prepare(pl, scene.clips, scene.irs, chunk_events=args.chunk_events)
+    batch = r.prepare(pl, scene.clips, scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
     n_ev = len(scene.clips)
     mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
                                      pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)
@@ -166,7 +167,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
-                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events},
+                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events, "lanes": args.lanes},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (pmc or {}).get(dominant),

@@ -82,6 +82,7 @@ SYMBOLS = {
     "al_fx_apply": (ct.c_int, [ct.c_int, _P, _P, ct.c_int64, _P, _P, _S]),
     "al_fx_frame_shuffle": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _P, ct.c_int32, _S]),
     "al_wrap_copy": (ct.c_int, [_P, ct.c_int64, _P, ct.c_int64, _S]),
+    "al_pack_irs_f64": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),
     "al_noise_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_noise_irfft": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
     "al_scale_matrix_rows": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _S]),

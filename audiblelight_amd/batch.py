@@ -1,0 +1,178 @@
+"""Batch driver: keep one MI355X busy over many scenes.
+
+The reference's dataset scripts render scenes in a serial loop (scripts/generate/benchmark.py:44-77,
+scripts/seld/generate_dataset.py:96-260) and write one WAV per microphone (core.py:1840-1847).  Here the
+stages of consecutive scenes overlap:
+
+    scene i+1:  host planning + pinned staging + H2D copy      (copy stream)
+    scene i  :  render + mixdown                                (compute stream)
+    scene i-1:  D2H of scene.audio + WAV encode                 (download stream + writer thread)
+
+Only plumbing lives here (torch streams/events, pinned buffers, a thread for file I/O); all arithmetic is
+in the kernels behind the C ABI.
+"""
+from __future__ import annotations
+
+import os
+import queue
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+from . import engine
+from . import plan as planning
+
+
+@dataclass
+class SceneJob:
+    """One microphone of one scene, described by arrays already in host memory."""
+    specs: Sequence[planning.EventSpec]
+    clips: Sequence[np.ndarray]
+    irs: np.ndarray                 # (C, N_total, L) float32 or float64 (WorldState.get_irs() layout)
+    starts: Sequence[float]
+    ends: Sequence[float]
+    duration: float
+    sample_rate: int
+    name: str = "scene"
+    ambience: Sequence = ()         # [(device noise buffer, device scalar)] prepared by the caller, optional
+
+
+@dataclass
+class BatchReport:
+    n_scenes: int = 0
+    scene_seconds: float = 0.0
+    wall_s: float = 0.0
+    h2d_bytes: int = 0
+    d2h_bytes: int = 0
+    files: List[str] = field(default_factory=list)
+
+    @property
+    def scene_seconds_per_second(self) -> float:
+        return self.scene_seconds / self.wall_s if self.wall_s > 0 else 0.0
+
+
+class BatchDriver:
+    """Pipelined rendering of a stream of SceneJobs on one GPU."""
+
+    def __init__(self, renderer: Optional[engine.Renderer] = None, depth: int = 2):
+        self.r = renderer or engine.Renderer()
+        if not hasattr(self.r.mem, "torch"):
+            raise RuntimeError("BatchDriver needs the torch/ROCm memory provider")
+        self.torch = self.r.mem.torch
+        self.depth = max(1, depth)
+        dev = self.r.mem.device
+        self.copy_stream = self.torch.cuda.Stream(device=dev)
+        self.down_stream = self.torch.cuda.Stream(device=dev)
+
+    # -- stage 1: host planning + asynchronous upload on the copy stream
+    def _stage(self, job: SceneJob):
+        torch, r = self.torch, self.r
+        c, n, l = job.irs.shape
+        pl = planning.plan_batch(job.specs, c, l, job.sample_rate)
+        n_ev = len(job.clips)
+        mix_plan = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n_ev,
+                                         pl.events["out_off"], list(range(n_ev)), job.duration, job.sample_rate, c)
+        audio_host = torch.from_numpy(r.pack_audio(pl, job.clips)).pin_memory()
+        irs_host = torch.from_numpy(np.ascontiguousarray(job.irs).reshape(-1))
+        if not irs_host.is_pinned():
+            irs_host = irs_host.pin_memory()
+        lp = (l + 3) // 4 * 4
+        with torch.cuda.stream(self.copy_stream):
+            irs_raw = irs_host.to(r.mem.device, non_blocking=True)
+            if job.irs.dtype == np.float64 or lp != l:
+                if job.irs.dtype != np.float64:
+                    irs_raw = irs_raw.double()
+                irs_dev = torch.empty(c * n * lp, dtype=torch.float32, device=r.mem.device)
+                import ctypes as ct
+                r.lib.call("al_pack_irs_f64", irs_raw.data_ptr(), irs_dev.data_ptr(), c * n, l, lp,
+                           ct.c_void_p(self.copy_stream.cuda_stream))
+            else:
+                irs_dev = irs_raw
+            audio_dev = audio_host.to(r.mem.device, non_blocking=True)
+            ready = torch.cuda.Event()
+            ready.record(self.copy_stream)
+        h2d = irs_host.numel() * irs_host.element_size() + audio_host.numel() * 4
+        return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=(n * lp, lp), audio=audio_dev, ready=ready,
+                    keep=(audio_host, irs_host, irs_raw), h2d=h2d)
+
+    # -- stage 2: kernels on the current (compute) stream
+    def _render(self, st):
+        torch, r = self.torch, self.r
+        cur = torch.cuda.current_stream(r.mem.device)
+        cur.wait_event(st["ready"])
+        batch = r.prepare(st["plan"], st["job"].clips, st["irs"], st["strides"], audio_dev=st["audio"])
+        res = batch.run()
+        scene = r.prepare_mixdown(st["mix"], res, st["job"].ambience).run()
+        done = torch.cuda.Event()
+        done.record(cur)
+        st.update(result=res, scene=scene, done=done, batch=batch)
+        return st
+
+    # -- stage 3: D2H on the download stream into pinned memory
+    def _download(self, st):
+        torch = self.torch
+        c, t = st["mix"].n_capsules, st["mix"].n_samples
+        host = torch.empty(c * t, dtype=torch.float32).pin_memory()
+        with torch.cuda.stream(self.down_stream):
+            self.down_stream.wait_event(st["done"])
+            host.copy_(st["scene"][: c * t], non_blocking=True)
+            landed = torch.cuda.Event()
+            landed.record(self.down_stream)
+        st.update(host=host, landed=landed)
+        return st
+
+    def run(self, jobs: Iterable[SceneJob], output_dir: Optional[str] = None,
+            on_scene: Optional[Callable[[str, np.ndarray], None]] = None, check_finite: bool = True) -> BatchReport:
+        """Render all jobs; per scene either write ``<output_dir>/<name>.wav`` (float32, (T, C) interleaved like
+        soundfile.write(audio.T) in core.py:1840-1847) or hand the (C, T) array to ``on_scene``."""
+        rep = BatchReport()
+        sink: "queue.Queue" = queue.Queue(maxsize=self.depth + 1)
+
+        def writer():
+            while True:
+                item = sink.get()
+                if item is None:
+                    return
+                st = item
+                st["landed"].synchronize()
+                if check_finite:
+                    st["result"].check_finite()
+                c, t = st["mix"].n_capsules, st["mix"].n_samples
+                arr = st["host"].numpy().reshape(c, t)
+                if output_dir is not None:
+                    from scipy.io import wavfile
+
+                    path = os.path.join(output_dir, f"{st['job'].name}.wav")
+                    wavfile.write(path, st["job"].sample_rate, arr.T)
+                    rep.files.append(path)
+                if on_scene is not None:
+                    on_scene(st["job"].name, arr)
+                rep.d2h_bytes += arr.nbytes
+
+        if output_dir is not None:
+            os.makedirs(output_dir, exist_ok=True)
+        th = threading.Thread(target=writer, daemon=True)
+        th.start()
+        t0 = time.perf_counter()
+        staged = None
+        it = iter(jobs)
+        nxt = next(it, None)
+        if nxt is not None:
+            staged = self._stage(nxt)
+        while staged is not None:
+            cur = staged
+            nxt = next(it, None)
+            staged = self._stage(nxt) if nxt is not None else None   # upload of scene i+1 overlaps the render of scene i
+            st = self._download(self._render(cur))
+            rep.n_scenes += 1
+            rep.scene_seconds += cur["job"].duration
+            rep.h2d_bytes += cur["h2d"]
+            sink.put(st)
+        sink.put(None)
+        th.join()
+        self.torch.cuda.synchronize(self.r.mem.device)
+        rep.wall_s = time.perf_counter() - t0
+        return rep

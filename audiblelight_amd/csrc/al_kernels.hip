@@ -536,6 +536,12 @@ __global__ __launch_bounds__(256) void k_scale_matrix_rows(float *x, int64_t col
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cols; i += (int64_t)gridDim.x * 256) row[i] *= s;
 }
 
+__global__ __launch_bounds__(256) void k_pack_irs_f64(const double *src, float *dst, int len, int pitch) {
+  const double *row = src + (int64_t)blockIdx.y * len;
+  float *out = dst + (int64_t)blockIdx.y * pitch;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < pitch; t += gridDim.x * 256) out[t] = t < len ? (float)row[t] : 0.f;
+}
+
 __global__ __launch_bounds__(256) void k_wrap_copy(const float *src, int64_t m, float *dst, int64_t n) {
   for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) dst[t] = src[t % m];
 }
@@ -853,6 +859,15 @@ int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scal
   hipLaunchKernelGGL(al::k_scale_matrix_rows, dim3((unsigned)(blocks < 2048 ? blocks : 2048), rows), dim3(256), 0,
                      (hipStream_t)stream, x, cols, scale);
   return check_launch("k_scale_matrix_rows");
+}
+
+int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream) {
+  if (!src || !dst || rows <= 0 || len <= 0 || dst_pitch < len || (dst_pitch & 3) || rows > 0x7fffffff)
+    return fail(AL_E_BADARG, "bad pack_irs arguments");
+  const int bx = (dst_pitch + 255) / 256;
+  hipLaunchKernelGGL(al::k_pack_irs_f64, dim3(bx < 64 ? bx : 64, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst,
+                     len, dst_pitch);
+  return check_launch("k_pack_irs_f64");
 }
 
 int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream) {

@@ -107,6 +107,13 @@ class Renderer:
     def upload_irs(self, irs: np.ndarray):
         c, n, l = irs.shape
         lp = (l + 3) // 4 * 4
+        if irs.dtype == np.float64 and n > 0 and irs.size >= (1 << 20):
+            # big float64 tensors (what WorldState.get_irs() returns): copy as they are, convert on the device
+            raw = self.mem.upload(np.ascontiguousarray(irs).reshape(-1))
+            dev = self.mem.empty(c * n * lp)
+            self.lib.call("al_pack_irs_f64", self.mem.ptr(raw), self.mem.ptr(dev), c * n, l, lp, self.mem.stream())
+            self.mem.synchronize()
+            return dev, (n * lp, lp)
         host = np.zeros((c, max(n, 1), lp), dtype=np.float32)
         host[:, :n, :l] = irs
         return self.mem.upload(host.reshape(-1)), (n * lp if n else lp, lp)
@@ -118,7 +125,8 @@ class Renderer:
         return host
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
-                chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1) -> "PreparedBatch":
+                chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
+                audio_dev=None) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
@@ -135,7 +143,8 @@ class Renderer:
         y_blocks = max(max(c["yspec_blocks"] for c in chunks), 1)
         lanes = max(1, min(int(lanes), len(chunks)))
         bufs = dict(
-            audio=mem.upload(self.pack_audio(plan, clips)), ir=irs, events=mem.upload(plan.events),
+            audio=audio_dev if audio_dev is not None else mem.upload(self.pack_audio(plan, clips)), ir=irs,
+            events=mem.upload(plan.events),
             streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
             wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),

@@ -76,6 +76,8 @@ def main():
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
     ap.add_argument("--cpu-events", type=int, default=6, help="events timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
+                    help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
     args = ap.parse_args()
 
@@ -174,6 +176,17 @@ def main():
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                      "hbm_bytes_per_launch_pmc": pmc},
     }
+    if args.end_to_end > 0:
+        from audiblelight_amd import batch as batch_mod
+
+        jobs = [batch_mod.SceneJob(specs=scene.specs, clips=scene.clips, irs=scene.irs, starts=scene.starts, ends=scene.ends,
+                                   duration=scene.duration, sample_rate=scene.sr, name=f"s{i}") for i in range(args.end_to_end)]
+        rep = batch_mod.BatchDriver(r).run(jobs, on_scene=lambda name, arr: None)
+        out["end_to_end"] = {"value": rep.scene_seconds_per_second, "unit": "scene-seconds/s", "scenes": rep.n_scenes,
+                             "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
+                             "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
+                             "note": "host float32 clips+IRs -> pinned staging -> H2D -> render -> D2H of scene.audio, pipelined "
+                                     "over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
     if args.gather and world > 1:
         from audiblelight_amd import distributed
 

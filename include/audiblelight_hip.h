@@ -211,6 +211,11 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
 /* x[r, :] *= scale[r]: per-channel peak normalisation (ambience.py:211-214) after al_row_stats. */
 int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream);
 
+/* IR ingest: WorldState.get_irs() hands out float64 (C, N, L) (worldstate.py:2183-2255); this
+ * converts to the float32 layout al_batch wants (row pitch `dst_pitch` >= L, multiple of 4, pad zeroed) on the device,
+ * so the host never casts 1.6 GB per scene.  rows = C * N. */
+int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream);
+
 /* dst[t] = src[t mod m] for t < n: np.pad(..., mode="wrap") of Augmentation.process. */
 int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream);
 

@@ -66,19 +66,29 @@ class BatchDriver:
         dev = self.r.mem.device
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
+        self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
+
+    def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
+        key = (tag, dtype, int(numel))
+        pool = self._pinned.setdefault(key, [])
+        while len(pool) <= slot:
+            pool.append(self.torch.empty(int(numel), dtype=dtype).pin_memory())
+        return pool[slot]
 
     # -- stage 1: host planning + asynchronous upload on the copy stream
-    def _stage(self, job: SceneJob):
+    def _stage(self, job: SceneJob, slot: int = 0):
         torch, r = self.torch, self.r
         c, n, l = job.irs.shape
         pl = planning.plan_batch(job.specs, c, l, job.sample_rate)
         n_ev = len(job.clips)
         mix_plan = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n_ev,
                                          pl.events["out_off"], list(range(n_ev)), job.duration, job.sample_rate, c)
-        audio_host = torch.from_numpy(r.pack_audio(pl, job.clips)).pin_memory()
-        irs_host = torch.from_numpy(np.ascontiguousarray(job.irs).reshape(-1))
-        if not irs_host.is_pinned():
-            irs_host = irs_host.pin_memory()
+        packed = torch.from_numpy(r.pack_audio(pl, job.clips))
+        audio_host = self._pinned_buffer("audio", packed.dtype, packed.numel(), slot)
+        audio_host.copy_(packed)
+        flat = torch.from_numpy(np.ascontiguousarray(job.irs).reshape(-1))
+        irs_host = self._pinned_buffer("irs", flat.dtype, flat.numel(), slot)
+        irs_host.copy_(flat)   # host memcpy into page-locked staging: the host-side cost of the boundary
         lp = (l + 3) // 4 * 4
         with torch.cuda.stream(self.copy_stream):
             irs_raw = irs_host.to(r.mem.device, non_blocking=True)
@@ -96,7 +106,7 @@ class BatchDriver:
             ready.record(self.copy_stream)
         h2d = irs_host.numel() * irs_host.element_size() + audio_host.numel() * 4
         return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=(n * lp, lp), audio=audio_dev, ready=ready,
-                    keep=(audio_host, irs_host, irs_raw), h2d=h2d)
+                    keep=(audio_host, irs_host, irs_raw), h2d=h2d, slot=slot)
 
     # -- stage 2: kernels on the current (compute) stream
     def _render(self, st):
@@ -115,7 +125,7 @@ class BatchDriver:
     def _download(self, st):
         torch = self.torch
         c, t = st["mix"].n_capsules, st["mix"].n_samples
-        host = torch.empty(c * t, dtype=torch.float32).pin_memory()
+        host = self._pinned_buffer("scene", torch.float32, c * t, st.get("slot", 0))
         with torch.cuda.stream(self.down_stream):
             self.down_stream.wait_event(st["done"])
             host.copy_(st["scene"][: c * t], non_blocking=True)
@@ -160,12 +170,18 @@ class BatchDriver:
         staged = None
         it = iter(jobs)
         nxt = next(it, None)
+        n_slots = self.depth + 2   # staging slots in flight: being filled, being rendered, being written
+        index = 0
         if nxt is not None:
-            staged = self._stage(nxt)
+            staged = self._stage(nxt, index % n_slots)
         while staged is not None:
             cur = staged
             nxt = next(it, None)
-            staged = self._stage(nxt) if nxt is not None else None   # upload of scene i+1 overlaps the render of scene i
+            index += 1
+            # upload of scene i+1 overlaps the render of scene i; a slot is reused only after its scene was written
+            while nxt is not None and sink.qsize() > self.depth:
+                time.sleep(0.0005)
+            staged = self._stage(nxt, index % n_slots) if nxt is not None else None
             st = self._download(self._render(cur))
             rep.n_scenes += 1
             rep.scene_seconds += cur["job"].duration

@@ -17,6 +17,7 @@ import os
 import queue
 import threading
 import time
+from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Callable, Iterable, List, Optional, Sequence
 
@@ -67,6 +68,19 @@ class BatchDriver:
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
         self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
+        self._pool = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2))))
+
+    def _parallel_copy(self, dst, src) -> None:
+        """dst.copy_(src) split over the worker threads (a single thread moves ~8 GB/s, a scene's IRs are ~0.8 GB)."""
+        n = dst.numel()
+        parts = self._pool._max_workers
+        step = -(-n // parts)
+        if n < (1 << 22):
+            dst.copy_(src)
+            return
+        futs = [self._pool.submit(lambda a, b: dst[a:b].copy_(src[a:b]), i, min(i + step, n)) for i in range(0, n, step)]
+        for f in futs:
+            f.result()
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
         key = (tag, dtype, int(numel))
@@ -88,7 +102,7 @@ class BatchDriver:
         audio_host.copy_(packed)
         flat = torch.from_numpy(np.ascontiguousarray(job.irs).reshape(-1))
         irs_host = self._pinned_buffer("irs", flat.dtype, flat.numel(), slot)
-        irs_host.copy_(flat)   # host memcpy into page-locked staging: the host-side cost of the boundary
+        self._parallel_copy(irs_host, flat)   # host memcpy into page-locked staging: the host-side cost of the boundary
         lp = (l + 3) // 4 * 4
         with torch.cuda.stream(self.copy_stream):
             irs_raw = irs_host.to(r.mem.device, non_blocking=True)

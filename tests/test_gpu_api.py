@@ -29,6 +29,7 @@ test_event_fx_chain_and_dict_roundtrip = scenarios.test_event_fx_chain_and_dict_
 test_powerlaw_noise_matches_reference = scenarios.test_powerlaw_noise_matches_reference
 test_powerlaw_misc_and_ambience_class = scenarios.test_powerlaw_misc_and_ambience_class
 test_scene_with_device_ambience = scenarios.test_scene_with_device_ambience
+test_two_microphones_with_different_capsule_counts = scenarios.test_two_microphones_with_different_capsule_counts
 
 
 def test_large_noise_lengths_statistics():

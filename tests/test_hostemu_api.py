@@ -224,3 +224,23 @@ def test_scene_with_device_ambience(golden):
         bad = build_g8_scene(golden, with_ambience=False)
         bad.add_ambience(amb.Ambience(channels=4, duration=1.0, alias="a0", noise="white", sample_rate=8000))
         bad.generate()
+
+
+def test_two_microphones_with_different_capsule_counts(golden):
+    """render_audio_for_all_scene_events loops microphones (synthesize.py:653-675): one batch per microphone."""
+    rng = np.random.default_rng(2)
+    sr = 8000
+    irs = {"mic000": rng.standard_normal((4, 3, 300)), "mic001": rng.standard_normal((2, 3, 300))}
+    scene = core.Scene(1.0, core.StaticIRState(irs), sample_rate=sr, ref_db=-60)
+    clips = [rng.standard_normal(n).astype(np.float32) for n in (2000, 1500)]
+    scene.add_event(core.Event("a", clips[0], sr, snr=10.0, scene_start=0.1, n_emitters=1))
+    scene.add_event(core.Event("b", clips[1], sr, snr=20.0, scene_start=0.5, n_emitters=2))
+    out = scene.generate()
+    assert out["mic000"].shape == (4, 8000) and out["mic001"].shape == (2, 8000)
+    for mic, h in irs.items():
+        ev_a, ev_b = scene.events["a"], scene.events["b"]
+        want_a = orc.render_event(ev_a.load_audio(), h[:, :1, :], 10.0, ref_db=-60, sr=sr)["spatial"]
+        want_b = orc.render_event(ev_b.load_audio(), h[:, 1:3, :], 20.0, ref_db=-60, is_moving=True, duration=ev_b.duration, sr=sr)["spatial"]
+        assert rel_rms(ev_a.spatial_audio[mic], want_a) < TOL and rel_rms(ev_b.spatial_audio[mic], want_b) < TOL
+        ref = orc.mix_scene([want_a, want_b], [(0.1, ev_a.scene_end), (0.5, ev_b.scene_end)], 1.0, sr, keep_padded=False)["scene"]
+        assert rel_rms(out[mic], ref) < TOL

@@ -206,3 +206,47 @@ class BatchDriver:
         self.torch.cuda.synchronize(self.r.mem.device)
         rep.wall_s = time.perf_counter() - t0
         return rep
+
+
+# ----------------------------------------------------------------------------- many small scenes in one launch sequence
+def merge_jobs(jobs: Sequence[SceneJob]):
+    """Concatenate several scenes that share (C, Lir, sample rate) into ONE event batch (cfg4: BASELINE configs[3]).
+
+    Small scenes are launch-bound when rendered one by one; their events are independent, so they can share one
+    launch sequence: clips are concatenated, IR tensors are concatenated along the emitter axis and every event's
+    ``emitter0`` is offset.  Returns (specs, clips, irs, event_ranges) with event_ranges[i] = (first, count) of scene i.
+    """
+    if not jobs:
+        raise ValueError("no jobs")
+    c, _, l = jobs[0].irs.shape
+    sr = jobs[0].sample_rate
+    specs, clips, ranges, col = [], [], [], 0
+    for job in jobs:
+        if job.irs.shape[0] != c or job.irs.shape[2] != l or job.sample_rate != sr:
+            raise ValueError("merge_jobs needs equal capsule count, IR length and sample rate")
+        ranges.append((len(specs), len(job.specs)))
+        for sp, clip in zip(job.specs, job.clips):
+            specs.append(planning.EventSpec(n_samples=sp.n_samples, n_emitters=sp.n_emitters, snr=sp.snr,
+                                            emitter0=col + sp.emitter0, is_moving=sp.is_moving, duration=sp.duration,
+                                            gain=sp.gain, ref_db=sp.ref_db, stft_len=sp.stft_len))
+            clips.append(clip)
+        col += job.irs.shape[1]
+    irs = np.concatenate([np.asarray(j.irs, dtype=np.float32) for j in jobs], axis=1)
+    return specs, clips, irs, ranges
+
+
+def render_merged(renderer: engine.Renderer, jobs: Sequence[SceneJob]) -> List[np.ndarray]:
+    """Render the scenes of ``merge_jobs`` with one render launch sequence and one mixdown launch per scene."""
+    specs, clips, irs, ranges = merge_jobs(jobs)
+    c, l = irs.shape[0], irs.shape[2]
+    pl = planning.plan_batch(specs, c, l, jobs[0].sample_rate)
+    res = renderer.render(pl, clips, irs)
+    res.check_finite()
+    out = []
+    for job, (e0, n) in zip(jobs, ranges):
+        mix = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n,
+                                    pl.events["out_off"][e0: e0 + n], list(range(e0, e0 + n)), job.duration,
+                                    job.sample_rate, c)
+        dev = renderer.mixdown(mix, res, job.ambience)
+        out.append(renderer.mem.download(dev)[: c * mix.n_samples].reshape(c, mix.n_samples))
+    return out

@@ -39,29 +39,18 @@ def test_cfg3_moving_sources(gpu):
 
 
 def test_cfg4_scene_batch_in_one_launch(gpu):
-    """Several independent scenes share one launch sequence: events concatenated, IR columns offset."""
-    from audiblelight_amd import plan as planning, synthetic
+    """Several independent scenes share one launch sequence (batch.merge_jobs): events concatenated, IR columns offset."""
+    from audiblelight_amd import batch, synthetic
 
     scenes = [synthetic.make_scene("cfg4", scene_index=i, scale=0.04, E=5, C=8) for i in range(3)]
-    specs, clips, col = [], [], 0
-    for sc in scenes:
-        for sp, clip in zip(sc.specs, sc.clips):
-            specs.append(planning.EventSpec(sp.n_samples, sp.n_emitters, sp.snr, emitter0=col + sp.emitter0, ref_db=sp.ref_db))
-            clips.append(clip)
-        col += sc.irs.shape[1]
-    irs = np.concatenate([sc.irs for sc in scenes], axis=1)
-    pl = planning.plan_batch(specs, 8, scenes[0].ir_len, scenes[0].sr)
-    res = gpu.render(pl, clips, irs)
-    e0 = 0
-    for sc in scenes:
+    jobs = [batch.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs, starts=sc.starts, ends=sc.ends, duration=sc.duration,
+                           sample_rate=sc.sr, name=f"s{i}") for i, sc in enumerate(scenes)]
+    outs = batch.render_merged(gpu, jobs)
+    for sc, got in zip(scenes, outs):
         n = len(sc.specs)
-        mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [8] * n,
-                                    pl.events["out_off"][e0: e0 + n], list(range(e0, e0 + n)), sc.duration, sc.sr, 8)
-        got = gpu.mem.download(gpu.mixdown(mix, res))[: 8 * mix.n_samples].reshape(8, -1)
         want = orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
                              keep_padded=False)["scene"]
         assert rel_rms(got, want) < TOL
-        e0 += n
 
 
 def test_cfg5_64ch_ambience_and_folded_fx(gpu):

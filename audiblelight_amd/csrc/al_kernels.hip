@@ -80,12 +80,16 @@ template <> struct BinVec<2> {
   }
 };
 
-template <int KT, int PT, int VB>
+// KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
+// Workgroups of one bin tile share blockIdx.x, hence (round-robin dispatch) an XCD and its L2, and the tiles of one
+// (event, capsule) are adjacent in dispatch order: the second..n-th read of the partition spectra hits L2.
+template <int KT, int PT, int VB, bool KSPLIT = false>
 __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   using V = BinVec<VB>;
   const int M = 1 << b.log2_block;
   const int f = (blockIdx.x * 256 + threadIdx.x) * VB;
-  const int c = blockIdx.y;
+  const int n_ktiles = KSPLIT ? (b.max_blocks + KT - 1) / KT : 1;
+  const int c = blockIdx.y / n_ktiles;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
@@ -94,8 +98,10 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
   const int K = ev.n_blocks, P = b.n_partitions;
   const bool packed = (f == 0);  // bin 0 holds (DC, Nyquist): two independent real products
+  const int k_first = KSPLIT ? (blockIdx.y % n_ktiles) * KT : 0;
+  const int k_limit = KSPLIT ? min(K, k_first + KT) : K;
 
-  for (int k0 = 0; k0 < K; k0 += KT) {
+  for (int k0 = k_first; k0 < k_limit; k0 += KT) {
     V acc[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
@@ -630,7 +636,16 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
 #define AL_MAC(KT_, PT_, VB_) \
   hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \
                      (hipStream_t)stream, *b)
-  if (variant == 1) AL_MAC(12, 12, 1);
+#define AL_MAC_KS(KT_, PT_, VB_) \
+  hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_, true>), \
+                     dim3(bins / (256 * VB_), b->n_capsules * ((b->max_blocks + KT_ - 1) / KT_), b->n_events), dim3(256), 0, \
+                     (hipStream_t)stream, *b)
+  if (variant == 11) AL_MAC_KS(12, 12, 2);
+  else if (variant == 12) AL_MAC_KS(8, 12, 2);
+  else if (variant == 13) AL_MAC_KS(12, 12, 1);
+  else if (variant == 14) AL_MAC_KS(6, 12, 2);
+  else if (variant == 15) AL_MAC_KS(24, 12, 1);
+  else if (variant == 1) AL_MAC(12, 12, 1);
   else if (variant == 2) AL_MAC(12, 12, 2);
   else if (variant == 3) AL_MAC(8, 12, 2);
   else if (variant == 4) AL_MAC(24, 12, 2);
@@ -641,6 +656,7 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   else if (wide_p) AL_MAC(8, 12, 1);
   else AL_MAC(8, 4, 1);
 #undef AL_MAC
+#undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
   // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
   if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS) {

@@ -646,12 +646,12 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   else if (variant == 14) AL_MAC_KS(6, 12, 2);
   else if (variant == 15) AL_MAC_KS(24, 12, 1);
   else if (variant == 1) AL_MAC(12, 12, 1);
-  else if (variant == 2) AL_MAC(12, 12, 2);
+  else if (variant == 2) AL_MAC(12, 12, 2);  // k-tiles looped inside the thread
   else if (variant == 3) AL_MAC(8, 12, 2);
   else if (variant == 4) AL_MAC(24, 12, 2);
   else if (variant == 5) AL_MAC(8, 12, 1);
   else if (variant == 6) AL_MAC(24, 12, 1);
-  else if (wide_k && wide_p && bins >= 512) AL_MAC(12, 12, 2);  // fastest on cfg2 (profiles/r01_mac_variants.txt)
+  else if (wide_k && wide_p && bins >= 512) AL_MAC_KS(12, 12, 2);  // fastest on cfg2 (profiles/r01_mac_variants.txt)
   else if (wide_k) AL_MAC(24, 4, 1);
   else if (wide_p) AL_MAC(8, 12, 1);
   else AL_MAC(8, 4, 1);

@@ -381,7 +381,8 @@ constexpr int ROW_CHUNK = 16384;  // samples per partial of k_row_stats
 
 __global__ __launch_bounds__(256) void k_row_stats(const float *x, int64_t cols, float *partials) {
   __shared__ float red[48];
-  const int chunk = blockIdx.x, r = blockIdx.y;
+  const int nchunks = (int)((cols + ROW_CHUNK - 1) / ROW_CHUNK);
+  const int chunk = blockIdx.x % nchunks, r = blockIdx.x / nchunks;  // rows may exceed the 65535 limit of grid.y
   const int64_t lo = (int64_t)chunk * ROW_CHUNK, hi = lo + ROW_CHUNK < cols ? lo + ROW_CHUNK : cols;
   const float *row = x + (int64_t)r * cols;
   float asum = 0.f, amax = 0.f, bad = 0.f, sq = 0.f;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(256) void k_row_stats(const float *x, int64_t cols,
   float z0 = 0.f, z1 = 0.f;
   block_reduce3(sq, z0, z1, red, threadIdx.x, 256);
   if (threadIdx.x == 0) {
-    float *pp = partials + 4 * ((int64_t)r * gridDim.x + chunk);
+    float *pp = partials + 4 * ((int64_t)r * nchunks + chunk);
     pp[0] = asum;
     pp[1] = amax;
     pp[2] = bad;
@@ -538,14 +539,14 @@ __global__ __launch_bounds__(256) void k_frame_shuffle(const float *src, float *
 
 __global__ __launch_bounds__(256) void k_scale_matrix_rows(float *x, int64_t cols, const float *scale) {
   const float s = scale[blockIdx.y];
-  float *row = x + (int64_t)blockIdx.y * cols;
+  float *row = x + (int64_t)blockIdx.y * cols;  // rows = channels of an ambience: far below grid.y's limit
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cols; i += (int64_t)gridDim.x * 256) row[i] *= s;
 }
 
 __global__ __launch_bounds__(256) void k_pack_irs_f64(const double *src, float *dst, int len, int pitch) {
-  const double *row = src + (int64_t)blockIdx.y * len;
-  float *out = dst + (int64_t)blockIdx.y * pitch;
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < pitch; t += gridDim.x * 256) out[t] = t < len ? (float)row[t] : 0.f;
+  const double *row = src + (int64_t)blockIdx.x * len;   // one workgroup per row: rows = C*N may exceed grid.y's 65535
+  float *out = dst + (int64_t)blockIdx.x * pitch;
+  for (int t = threadIdx.x; t < pitch; t += 256) out[t] = t < len ? (float)row[t] : 0.f;
 }
 
 __global__ __launch_bounds__(256) void k_wrap_copy(const float *src, int64_t m, float *dst, int64_t n) {
@@ -742,7 +743,8 @@ int64_t al_row_stats_partials(int32_t rows, int64_t cols) {
 int al_row_stats(const float *x, int32_t rows, int64_t cols, float *partials, double *out, al_stream_t stream) {
   if (!x || !partials || !out || rows <= 0 || cols <= 0) return fail(AL_E_BADARG, "bad row_stats arguments");
   const int nchunks = (int)((cols + al::ROW_CHUNK - 1) / al::ROW_CHUNK);
-  hipLaunchKernelGGL(al::k_row_stats, dim3(nchunks, rows), dim3(256), 0, (hipStream_t)stream, x, cols, partials);
+  if ((int64_t)nchunks * rows > 0x7fffffff) return fail(AL_E_BADARG, "row_stats: too many (row, chunk) pairs");
+  hipLaunchKernelGGL(al::k_row_stats, dim3((unsigned)(nchunks * rows)), dim3(256), 0, (hipStream_t)stream, x, cols, partials);
   if (int rc = check_launch("k_row_stats")) return rc;
   hipLaunchKernelGGL(al::k_row_stats_final, dim3(rows), dim3(64), 0, (hipStream_t)stream, partials, nchunks, out);
   return check_launch("k_row_stats_final");
@@ -870,7 +872,7 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
 }
 
 int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream) {
-  if (!x || !scale || rows <= 0 || cols <= 0) return fail(AL_E_BADARG, "bad scale_matrix_rows arguments");
+  if (!x || !scale || rows <= 0 || rows > 65535 || cols <= 0) return fail(AL_E_BADARG, "bad scale_matrix_rows arguments");
   const int64_t blocks = (cols + 255) / 256;
   hipLaunchKernelGGL(al::k_scale_matrix_rows, dim3((unsigned)(blocks < 2048 ? blocks : 2048), rows), dim3(256), 0,
                      (hipStream_t)stream, x, cols, scale);
@@ -880,9 +882,7 @@ int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scal
 int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream) {
   if (!src || !dst || rows <= 0 || len <= 0 || dst_pitch < len || (dst_pitch & 3) || rows > 0x7fffffff)
     return fail(AL_E_BADARG, "bad pack_irs arguments");
-  const int bx = (dst_pitch + 255) / 256;
-  hipLaunchKernelGGL(al::k_pack_irs_f64, dim3(bx < 64 ? bx : 64, (unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst,
-                     len, dst_pitch);
+  hipLaunchKernelGGL(al::k_pack_irs_f64, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst, len, dst_pitch);
   return check_launch("k_pack_irs_f64");
 }
 

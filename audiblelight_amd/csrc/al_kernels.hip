@@ -93,7 +93,6 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
-  if (ev.n_streams == 1 && (b.flags & AL_FLAG_HLDS) && b.n_partitions <= 24) return;                // k_spectral_mac_hlds
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
@@ -167,92 +166,6 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk)
       if (k0 + kk < K) acc[kk].store(Y + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K + k0 + kk) * M + f);
-  }
-}
-
-// ------------------------------------------------------------------ 4a. static events, partition spectra staged in LDS
-// Variant of the tile kernel for single-stream (static) events: the thread first copies the P partition spectra of
-// its own bins into LDS (its private column: no barrier needed), then walks the k-tiles reading them from LDS, so
-// HBM sees every H value once while the register footprint stays that of one tile.
-template <int KT, int PT, int VB, int PMAX>
-__global__ __launch_bounds__(256) void k_spectral_mac_hlds(al_batch b) {
-  using V = BinVec<VB>;
-  __shared__ float2 hs[PMAX][256 * VB];
-  const int M = 1 << b.log2_block;
-  const int f = (blockIdx.x * 256 + threadIdx.x) * VB;
-  const int c = blockIdx.y;
-  const al_event ev = b.events[b.event0 + blockIdx.z];
-  if (ev.n_streams != 1) return;
-  const al_stream st = b.streams[ev.stream0];
-  const int K = ev.n_blocks, P = b.n_partitions;
-  const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
-  const float2 *__restrict__ hp = reinterpret_cast<const float2 *>(b.hspec) +
-                                  (((int64_t)(st.emitter - b.emitter0) * b.n_capsules + c) * P) * M + f;
-  const float2 *__restrict__ xp = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
-  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K) * M + f;
-  const bool packed = (f == 0);
-  const float g = b.emitter_gain[st.emitter];
-  float2 *mine = &hs[0][threadIdx.x * VB];
-  for (int p = 0; p < P; ++p) {
-    V h = V::load(hp + (int64_t)p * M);
-    h.scale(g);
-    h.store(mine + (int64_t)p * 256 * VB);
-  }
-  if (jhi <= jlo) {
-    for (int k = 0; k < K; ++k) V::zero().store(Y + (int64_t)k * M);
-    return;
-  }
-  constexpr int XG = 8 / VB, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
-  for (int k0 = 0; k0 < K; k0 += KT) {
-    V acc[KT];
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
-    const int plo = max(0, k0 - jhi + 1), phi = min(P - 1, k0 + KT - 1 - jlo);
-    for (int p0 = plo; p0 <= phi; p0 += PT) {
-      V h[PT];
-#pragma unroll
-      for (int pp = 0; pp < PT; ++pp) {
-        h[pp] = V::load(mine + (int64_t)min(p0 + pp, phi) * 256 * VB);
-        h[pp].scale(p0 + pp <= phi ? 1.f : 0.f);
-      }
-      const int jbase = k0 - p0 - (PT - 1);
-      auto fetch = [&](int jj) -> V {
-        const int j = jbase + jj;
-        V x = V::load(xp + (int64_t)min(max(j, jlo), jhi - 1) * M);
-        x.scale((j >= jlo && j < jhi) ? 1.f : 0.f);
-        return x;
-      };
-      V xa[XG], xb[XG];
-      static_for<XG>([&](auto i_c) {
-        constexpr int i = decltype(i_c)::value;
-        if constexpr (i < NJ) xa[i] = fetch(i);
-      });
-      static_for<NG>([&](auto g_c) {
-        constexpr int g_ = decltype(g_c)::value;
-        static_for<XG>([&](auto i_c) {
-          constexpr int i = decltype(i_c)::value;
-          if constexpr ((g_ + 1) * XG + i < NJ) xb[i] = fetch((g_ + 1) * XG + i);
-        });
-        static_for<XG>([&](auto i_c) {
-          constexpr int i = decltype(i_c)::value;
-          constexpr int jj = g_ * XG + i;
-          if constexpr (jj < NJ) {
-            static_for<KT>([&](auto kk_c) {
-              constexpr int kk = decltype(kk_c)::value;
-              constexpr int pp = kk + (PT - 1) - jj;
-              if constexpr (pp >= 0 && pp < PT) acc[kk].fma(xa[i], h[pp], packed);
-            });
-          }
-        });
-        static_for<XG>([&](auto i_c) {
-          constexpr int i = decltype(i_c)::value;
-          if constexpr ((g_ + 1) * XG + i < NJ) xa[i] = xb[i];
-        });
-      });
-    }
-#pragma unroll
-    for (int kk = 0; kk < KT; ++kk)
-      if (k0 + kk < K) acc[kk].store(Y + (int64_t)(k0 + kk) * M);
   }
 }
 
@@ -719,24 +632,6 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers.
   // flags bits 8..11 select an experimental variant (0 = default).
   const int variant = (b->flags >> 8) & 15;
-  if ((b->flags & AL_FLAG_HLDS) && b->n_partitions <= 24) {
-    const int bins_ = 1 << b->log2_block;
-#define AL_MACL(KT_, PT_, VB_, PM_) \
-  hipLaunchKernelGGL((al::k_spectral_mac_hlds<KT_, PT_, VB_, PM_>), dim3(bins_ / (256 * VB_), b->n_capsules, b->n_events), \
-                     dim3(256), 0, (hipStream_t)stream, *b)
-    if (b->n_partitions <= 12) {
-      if (variant == 1) AL_MACL(12, 12, 1, 12);
-      else if (variant == 2) AL_MACL(8, 12, 2, 12);
-      else if (variant == 3) AL_MACL(24, 12, 1, 12);
-      else AL_MACL(12, 12, 2, 12);
-    } else {
-      if (variant == 1) AL_MACL(8, 12, 1, 24);
-      else if (variant == 2) AL_MACL(24, 12, 1, 24);
-      else AL_MACL(12, 12, 1, 24);
-    }
-#undef AL_MACL
-    if (int rc = check_launch("k_spectral_mac_hlds")) return rc;
-  }
   const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
   const int bins = 1 << b->log2_block;
 #define AL_MAC(KT_, PT_, VB_) \

@@ -61,8 +61,10 @@ template <> struct BinVec<1> {
   __device__ __forceinline__ static BinVec load(const float2 *p) { return BinVec{*p}; }
   __device__ __forceinline__ void store(float2 *p) const { *p = a; }
   __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; }
+  // BIN0: this wave may hold bin 0 (packed DC/Nyquist: two real products); every other wave takes the plain path
+  template <bool BIN0>
   __device__ __forceinline__ void fma(const BinVec &x, const BinVec &h, bool packed) {
-    if (packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
+    if (BIN0 && packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
   }
 };
 template <> struct BinVec<2> {
@@ -74,8 +76,9 @@ template <> struct BinVec<2> {
   }
   __device__ __forceinline__ void store(float2 *p) const { *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, c.x, c.y); }
   __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; c.x *= g; c.y *= g; }
+  template <bool BIN0>
   __device__ __forceinline__ void fma(const BinVec &x, const BinVec &h, bool packed) {
-    if (packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
+    if (BIN0 && packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
     cfma(c, x.c, h.c);
   }
 };
@@ -83,8 +86,8 @@ template <> struct BinVec<2> {
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
 // Workgroups of one bin tile share blockIdx.x, hence (round-robin dispatch) an XCD and its L2, and the tiles of one
 // (event, capsule) are adjacent in dispatch order: the second..n-th read of the partition spectra hits L2.
-template <int KT, int PT, int VB, bool KSPLIT = false>
-__global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
+template <int KT, int PT, int VB, bool KSPLIT, bool BIN0>
+__device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
   using V = BinVec<VB>;
   const int M = 1 << b.log2_block;
   const int f = (blockIdx.x * 256 + threadIdx.x) * VB;
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
               static_for<KT>([&](auto kk_c) {
                 constexpr int kk = decltype(kk_c)::value;
                 constexpr int pp = kk + (PT - 1) - jj;
-                if constexpr (pp >= 0 && pp < PT) acc[kk].fma(xa[i], h[pp], packed);
+                if constexpr (pp >= 0 && pp < PT) acc[kk].template fma<BIN0>(xa[i], h[pp], packed);
               });
             }
           });
@@ -169,14 +172,24 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   }
 }
 
+// Bin 0 needs two real products instead of a complex one.  Only the first wave of the first bin tile can hold it:
+// that wave runs the BIN0 instantiation (per-lane select), every other wave the plain complex path -- folding the
+// select into the common path costs two extra FMAs and two v_cndmask per product for EVERY bin (measured: 43 % of
+// the kernel's vector instructions).
+template <int KT, int PT, int VB, bool KSPLIT = false>
+__global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
+  if (blockIdx.x == 0 && threadIdx.x < 64) spectral_mac_body<KT, PT, VB, KSPLIT, true>(b);
+  else spectral_mac_body<KT, PT, VB, KSPLIT, false>(b);
+}
+
 // ------------------------------------------------------------------ 4b. accumulate for moving events
 // A moving event is N streams (one per IR) whose clips are only a few blocks long (the cross-fade window of
 // that IR) and whose first blocks j_lo are non-decreasing.  One thread owns one bin (pair) of one capsule and
 // walks the streams in order with a SLIDING window of W = NJW + PT - 1 output accumulators anchored at the
 // current stream's j_lo: blocks that fall behind the window are complete and are written out once.  Every H,
 // X and Y value moves exactly once and every register index is static.
-template <int NJW, int PT, int VB>
-__global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
+template <int NJW, int PT, int VB, bool BIN0>
+__device__ __forceinline__ void spectral_mac_moving_body(const al_batch &b, int4 *tab, float *gains) {
   using V = BinVec<VB>;
   constexpr int W = NJW + PT - 1;
   const int M = 1 << b.log2_block;
@@ -184,8 +197,6 @@ __global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
   const int c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 1 || ev.reserved != 1) return;  // static / dense events: k_spectral_mac
-  __shared__ int4 tab[64];    // {j_lo, n_j, emitter - emitter0, xspec_base - xspec_block0}
-  __shared__ float gains[64];
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * ev.n_blocks) * M + f;
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
 #pragma unroll
       for (int jj = 0; jj < NJW; ++jj)
 #pragma unroll
-        for (int pp = 0; pp < PT; ++pp) acc[jj + pp].fma(x[jj], h[pp], packed);
+        for (int pp = 0; pp < PT; ++pp) acc[jj + pp].template fma<BIN0>(x[jj], h[pp], packed);
     }
   }
 #pragma unroll
@@ -241,6 +252,15 @@ __global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
     if (kbase + w < K) acc[w].store(Y + (int64_t)(kbase + w) * M);
   // blocks beyond the last window (no stream reaches them) are zero
   for (int k = kbase + W; k < K; ++k) V::zero().store(Y + (int64_t)k * M);
+}
+
+template <int NJW, int PT, int VB>
+__global__ __launch_bounds__(256) void k_spectral_mac_moving(al_batch b) {
+  __shared__ int4 tab[64];    // {j_lo, n_j, emitter - emitter0, xspec_base - xspec_block0}
+  __shared__ float gains[64];
+  // both instantiations run the same barriers in the same order, so splitting the workgroup by wave is safe
+  if (blockIdx.x == 0 && threadIdx.x < 64) spectral_mac_moving_body<NJW, PT, VB, true>(b, tab, gains);
+  else spectral_mac_moving_body<NJW, PT, VB, false>(b, tab, gains);
 }
 
 // ------------------------------------------------------------------ 6. event levels

@@ -86,65 +86,6 @@ template <> struct BinVec<2> {
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
 // Workgroups of one bin tile share blockIdx.x, hence (round-robin dispatch) an XCD and its L2, and the tiles of one
 // (event, capsule) are adjacent in dispatch order: the second..n-th read of the partition spectra hits L2.
-// One (k-tile x p-tile) pair: acc[kk] += sum over the pair's anti-diagonals of X[j] * H[p].
-//   EDGE = false: hp points at partition p0, xp at signal block jbase, all PT partitions / KT+PT-1 blocks exist.
-//   EDGE = true : hp / xp are the stream's rows; loads are clamped into [.., phi] / [jlo, jhi) and masked.
-// The KT+PT-1 signal blocks are fetched in groups of XG, one group ahead of the FMAs that consume them.
-template <int KT, int PT, int VB, bool BIN0, bool EDGE>
-__device__ __forceinline__ void mac_tile_pair(BinVec<VB> (&acc)[KT], const float2 *__restrict__ hp, const float2 *__restrict__ xp,
-                                              int M, float g, int p0, int phi, int jbase, int jrange, bool packed) {
-  using V = BinVec<VB>;
-  const int jlo = jrange & 0xffff, jhi = jrange >> 16;
-  V h[PT];
-#pragma unroll
-  for (int pp = 0; pp < PT; ++pp) {
-    if (EDGE) {
-      h[pp] = V::load(hp + (int64_t)min(p0 + pp, phi) * M);  // unconditional load at a clamped partition
-      h[pp].scale((p0 + pp <= phi) ? g : 0.f);
-    } else {
-      h[pp] = V::load(hp + (int64_t)pp * M);
-      h[pp].scale(g);
-    }
-  }
-  constexpr int XG = 8 / VB, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
-  auto fetch = [&](int jj) -> V {
-    if (EDGE) {
-      const int j = jbase + jj;
-      V x = V::load(xp + (int64_t)min(max(j, jlo), jhi - 1) * M);
-      x.scale((j >= jlo && j < jhi) ? 1.f : 0.f);
-      return x;
-    }
-    return V::load(xp + (int64_t)jj * M);
-  };
-  V xa[XG], xb[XG];
-  static_for<XG>([&](auto i_c) {
-    constexpr int i = decltype(i_c)::value;
-    if constexpr (i < NJ) xa[i] = fetch(i);
-  });
-  static_for<NG>([&](auto g_c) {
-    constexpr int g_ = decltype(g_c)::value;
-    static_for<XG>([&](auto i_c) {  // prefetch group g+1
-      constexpr int i = decltype(i_c)::value;
-      if constexpr ((g_ + 1) * XG + i < NJ) xb[i] = fetch((g_ + 1) * XG + i);
-    });
-    static_for<XG>([&](auto i_c) {  // consume group g
-      constexpr int i = decltype(i_c)::value;
-      constexpr int jj = g_ * XG + i;
-      if constexpr (jj < NJ) {
-        static_for<KT>([&](auto kk_c) {
-          constexpr int kk = decltype(kk_c)::value;
-          constexpr int pp = kk + (PT - 1) - jj;
-          if constexpr (pp >= 0 && pp < PT) acc[kk].template fma<BIN0>(xa[i], h[pp], packed);
-        });
-      }
-    });
-    static_for<XG>([&](auto i_c) {
-      constexpr int i = decltype(i_c)::value;
-      if constexpr ((g_ + 1) * XG + i < NJ) xa[i] = xb[i];
-    });
-  });
-}
-
 template <int KT, int PT, int VB, bool KSPLIT, bool BIN0>
 __device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
   using V = BinVec<VB>;
@@ -178,13 +119,51 @@ __device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
       const float2 *hp = H + (((int64_t)(st.emitter - b.emitter0) * b.n_capsules + c) * P) * M + f;
       const float2 *xp = X + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
       for (int p0 = plo; p0 <= phi; p0 += PT) {
+        V h[PT];
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) {
+          // unconditional load at a clamped partition, zeroed by the select: keeps all PT loads in flight
+          h[pp] = V::load(hp + (int64_t)min(p0 + pp, phi) * M);
+          h[pp].scale((p0 + pp <= phi) ? g : 0.f);
+        }
         const int jbase = k0 - p0 - (PT - 1);  // signal block of anti-diagonal jj is jbase + jj
-        // interior tile pair (workgroup-uniform): every partition and every signal block of the pair exists, so the
-        // loads need no clamping and no masking -- about a third fewer instructions than the edge form
-        if (p0 + PT - 1 <= phi && jbase >= jlo && jbase + KT + PT - 2 < jhi)
-          mac_tile_pair<KT, PT, VB, BIN0, false>(acc, hp + (int64_t)p0 * M, xp + (int64_t)jbase * M, M, g, 0, 0, 0, 0, packed);
-        else
-          mac_tile_pair<KT, PT, VB, BIN0, true>(acc, hp, xp, M, g, p0, phi, jbase, jlo | (jhi << 16), packed);
+        // The KT+PT-1 signal blocks are fetched in groups of XG, one group ahead of the FMAs that
+        // consume them (explicit double buffer): the loads are L2 hits with ~1 us latency under load,
+        // and a wave that waits for them one by one is latency-bound, not bandwidth-bound.
+        constexpr int XG = 8 / VB, NJ = KT + PT - 1, NG = (NJ + XG - 1) / XG;
+        auto fetch = [&](int jj) -> V {
+          const int j = jbase + jj;
+          V x = V::load(xp + (int64_t)min(max(j, jlo), jhi - 1) * M);  // clamped, unconditional
+          x.scale((j >= jlo && j < jhi) ? 1.f : 0.f);
+          return x;
+        };
+        V xa[XG], xb[XG];
+        static_for<XG>([&](auto i_c) {
+          constexpr int i = decltype(i_c)::value;
+          if constexpr (i < NJ) xa[i] = fetch(i);
+        });
+        static_for<NG>([&](auto g_c) {
+          constexpr int g_ = decltype(g_c)::value;
+          static_for<XG>([&](auto i_c) {  // prefetch group g+1
+            constexpr int i = decltype(i_c)::value;
+            if constexpr ((g_ + 1) * XG + i < NJ) xb[i] = fetch((g_ + 1) * XG + i);
+          });
+          static_for<XG>([&](auto i_c) {  // consume group g
+            constexpr int i = decltype(i_c)::value;
+            constexpr int jj = g_ * XG + i;
+            if constexpr (jj < NJ) {
+              static_for<KT>([&](auto kk_c) {
+                constexpr int kk = decltype(kk_c)::value;
+                constexpr int pp = kk + (PT - 1) - jj;
+                if constexpr (pp >= 0 && pp < PT) acc[kk].template fma<BIN0>(xa[i], h[pp], packed);
+              });
+            }
+          });
+          static_for<XG>([&](auto i_c) {
+            constexpr int i = decltype(i_c)::value;
+            if constexpr ((g_ + 1) * XG + i < NJ) xa[i] = xb[i];
+          });
+        });
       }
     }
 #pragma unroll

@@ -141,6 +141,42 @@ class Scene:
     def add_ambience(self, ambience) -> None:
         self.ambience[ambience.alias] = ambience
 
+    # -- metadata round trip (reference core.py:2106-2243): everything except the samples themselves
+    def to_dict(self) -> dict:
+        return dict(duration=self.duration, sample_rate=self.sample_rate, ref_db=self.ref_db,
+                    microphones={k: m.n_capsules for k, m in self.state.microphones.items()},
+                    events={k: e.to_dict() for k, e in self.events.items()},
+                    ambience={k: a.to_dict() for k, a in self.ambience.items() if hasattr(a, "to_dict")})
+
+    def to_json(self, path: str) -> None:
+        import json
+
+        with open(path, "w") as fh:
+            json.dump(self.to_dict(), fh, indent=2)
+
+    @classmethod
+    def from_dict(cls, d: dict, clips: Dict[str, np.ndarray], irs: Dict[str, np.ndarray]) -> "Scene":
+        """Rebuild a scene from ``to_dict`` metadata plus the arrays it does not store: ``clips[event alias]`` (raw
+        mono audio) and ``irs[mic alias]`` ((C, N_total, L) tensors)."""
+        from . import ambience as amb_mod, augmentation as aug_mod
+
+        scene = cls(d["duration"], StaticIRState(irs), sample_rate=d["sample_rate"], ref_db=d["ref_db"])
+        for alias, ed in d["events"].items():
+            fx = [aug_mod.Augmentation.from_dict(a) for a in ed.get("augmentations", [])]
+            scene.add_event(Event(alias, clips[alias], ed["sample_rate"], snr=ed["snr"], scene_start=ed["scene_start"],
+                                  n_emitters=ed["n_emitters"], is_moving=ed["is_moving"], augmentations=fx,
+                                  class_label=ed.get("class_label")))
+        for alias, ad in d.get("ambience", {}).items():
+            scene.add_ambience(amb_mod.Ambience.from_dict(ad))
+        return scene
+
+    @classmethod
+    def from_json(cls, path: str, clips: Dict[str, np.ndarray], irs: Dict[str, np.ndarray]) -> "Scene":
+        import json
+
+        with open(path) as fh:
+            return cls.from_dict(json.load(fh), clips, irs)
+
     def generate(self, output_dir=None, audio: bool = True, audio_fname: str = "audio_out") -> Dict[str, np.ndarray]:
         """Render every event and mix the scene (core.py:1789-1874, audio branch); writes float32 WAV
         files ``<audio_fname>_<mic>.wav`` when ``output_dir`` is given."""

@@ -30,6 +30,7 @@ test_powerlaw_noise_matches_reference = scenarios.test_powerlaw_noise_matches_re
 test_powerlaw_misc_and_ambience_class = scenarios.test_powerlaw_misc_and_ambience_class
 test_scene_with_device_ambience = scenarios.test_scene_with_device_ambience
 test_two_microphones_with_different_capsule_counts = scenarios.test_two_microphones_with_different_capsule_counts
+test_scene_json_round_trip = scenarios.test_scene_json_round_trip
 
 
 def test_large_noise_lengths_statistics():

@@ -244,3 +244,18 @@ def test_two_microphones_with_different_capsule_counts(golden):
         assert rel_rms(ev_a.spatial_audio[mic], want_a) < TOL and rel_rms(ev_b.spatial_audio[mic], want_b) < TOL
         ref = orc.mix_scene([want_a, want_b], [(0.1, ev_a.scene_end), (0.5, ev_b.scene_end)], 1.0, sr, keep_padded=False)["scene"]
         assert rel_rms(out[mic], ref) < TOL
+
+
+def test_scene_json_round_trip(golden, tmp_path):
+    """Metadata round trip (reference core.py:2106-2243): a scene rebuilt from JSON + arrays renders identically."""
+    scene = build_g8_scene(golden, with_ambience=False)
+    scene.events["ev0"].register_augmentations([aug.Gain(8000, gain_db=-2.0), aug.Invert(8000)])
+    from audiblelight_amd import ambience as amb
+
+    scene.add_ambience(amb.Ambience(channels=4, duration=2.0, alias="a0", noise="white", ref_db=-65, sample_rate=8000))
+    first = scene.generate()["mic000"].copy()
+    path = str(tmp_path / "scene.json")
+    scene.to_json(path)
+    again = core.Scene.from_json(path, clips={a: e._raw for a, e in scene.events.items()}, irs=dict(scene.state.irs))
+    assert again.to_dict() == scene.to_dict()
+    np.testing.assert_array_equal(again.generate()["mic000"], first)

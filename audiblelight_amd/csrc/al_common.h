@@ -19,6 +19,16 @@ __device__ __forceinline__ void static_for(F &&f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
+// Returns x unchanged but unknown to the optimiser.  Used on the lane index at the top of a loop over blocks: the
+// lane-dependent addresses of the loop body would otherwise all be hoisted as loop invariants (two registers each)
+// and overflow the register file.
+__device__ __forceinline__ int opaque_lane(int x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  asm volatile("" : "+v"(x));
+#endif
+  return x;
+}
+
 // ------------------------------------------------------------------ block-wide reductions
 // sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
 __device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,

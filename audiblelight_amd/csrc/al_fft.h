@@ -367,17 +367,23 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[16], fl
 }
 
 template <int LOG2M>
-__device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ in, float2 (&v)[16], float2 *s,
-                                                    const float2 *__restrict__ tw, int tid, float scale) {
+__device__ __forceinline__ void real_pack_issue(const float2 *__restrict__ in, float2 (&yk)[8], float2 (&ym)[8], int tid) {
   constexpr int M = 1 << LOG2M, T = M / 16;
-  float2 yk[8], ym[8], w[8];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {  // all loads first: 24 in flight
+  for (int m = 0; m < 8; ++m) {  // global loads only: the caller decides what runs while they are in flight
     const int k = tid + T * m;
     yk[m] = in[k];
     ym[m] = in[k == 0 ? M / 2 : M - k];
-    w[m] = tw[k];
   }
+}
+
+template <int LOG2M>
+__device__ __forceinline__ void real_pack_finish(const float2 (&yk)[8], const float2 (&ym)[8], float2 (&v)[16], float2 *s,
+                                                 const float2 *__restrict__ tw, int tid, float scale) {
+  constexpr int M = 1 << LOG2M, T = M / 16;
+  float2 w[8];
+#pragma unroll
+  for (int m = 0; m < 8; ++m) w[m] = tw[tid + T * m];
   const float hs = 0.5f * scale;
 #pragma unroll
   for (int m = 0; m < 8; ++m) {
@@ -397,6 +403,14 @@ __device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ i
 #pragma unroll
   for (int m = 8; m < 16; ++m) v[m] = s[lds_pad(tid + T * m)];
   __syncthreads();
+}
+
+template <int LOG2M>
+__device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ in, float2 (&v)[16], float2 *s,
+                                                    const float2 *__restrict__ tw, int tid, float scale) {
+  float2 yk[8], ym[8];
+  real_pack_issue<LOG2M>(in, yk, ym, tid);
+  real_pack_finish<LOG2M>(yk, ym, v, s, tw, tid, scale);
 }
 
 // ---- Split transforms: one block of M = 2^LOG2M complex points done as TWO transforms of M/2 points by a

@@ -25,6 +25,54 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level para
 METRIC = "rendered scene-seconds/sec @48kHz, 32-ch mic, 64 events, 2s RIR; 1/2/4/8 GPU"
 
 
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _cpu_worker(job):
+    """One event through the oracle in a worker process (all-cores leg of the CPU baseline)."""
+    from oracle import synth_oracle as orc
+
+    clip, h, snr, ref_db, moving, duration, sr = job
+    t0 = time.perf_counter()
+    orc.render_event(clip, h, snr, ref_db, moving, duration, sr)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
+    """the oracle on `workers` host processes, one event each (events are independent, so a
+    scene's events spread over the cores); rate = workers events per wall time, scaled to the scene's event count."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+
+    jobs, work, full = [], 0, 0
+    for i in range(workers):
+        sp = scene.specs[i % len(scene.specs)]
+        n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
+        h = scene.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
+        jobs.append((scene.clips[i % len(scene.clips)], h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr))
+        work += max(n_used, 1)
+    for sp in scene.specs:
+        full += max(sp.n_emitters, 1)
+    # spawn, not fork: this process has initialised the GPU; a broken worker raises instead of hanging
+    with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:
+        list(pool.map(_cpu_worker, jobs))               # warm: imports, page faults
+        t0 = time.perf_counter()
+        list(pool.map(_cpu_worker, jobs))
+        wall = time.perf_counter() - t0
+    total = wall * full / work
+    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=workers, kind="port", cpu_model=cpu_model(),
+                sample=f"{workers} events of one {scene.name} scene rendered concurrently, one oracle process each "
+                       f"({wall:.1f} s wall), scaled linearly to the scene's events x IRs; mixdown not included")
+
+
 def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
     """Time the float64 numpy/scipy oracle (kind "port") on a bounded sample of the same workload."""
     from oracle import synth_oracle as orc
@@ -46,7 +94,7 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
     t_mix = time.perf_counter() - t0
     total = t_events * full_work / max(work, 1) + t_mix * len(scene.specs) / n_events
     moving = any(sp.is_moving for sp in scene.specs)
-    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port",
+    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port", cpu_model=cpu_model(),
                 sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene"
                        + (f" with {n_irs_cap} of {scene.specs[0].n_emitters} IRs each" if moving else "")
                        + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured, "
@@ -76,6 +124,8 @@ def main():
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
     ap.add_argument("--cpu-events", type=int, default=6, help="events timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-workers", type=int, default=0, metavar="N",
+                    help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64)")
     ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
                     help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate)")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
@@ -202,6 +252,9 @@ def main():
     if rank == 0:
         if world == 1 and args.cpu_events > 0:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))
+            if args.cpu_workers != 0:
+                workers = min(os.cpu_count() or 1, 64) if args.cpu_workers < 0 else args.cpu_workers
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(scene, workers)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

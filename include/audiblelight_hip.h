@@ -35,6 +35,7 @@ extern "C" {
 
 #define AL_FLAG_FORCE_SPLIT 4  /* opt-in: one block as two half-size transforms per workgroup (B >= 4096); slower on
                                  MI355X (profiles/r01_split_transforms.txt), kept for boxes with less LDS headroom */
+#define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
 
 #define AL_SPARSE_MAX_NJ 6          /* longest stream (in blocks) the sliding-window accumulate accepts */
 #define AL_SPARSE_MAX_PARTITIONS 24 /* most IR partitions it accepts */

@@ -162,7 +162,7 @@ class Renderer:
             n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
             n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
-            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | (int(os.environ.get("AL_MAC_VARIANT", "0")) << 8) | int(os.environ.get("AL_SPLIT_FLAGS", "0")), **lane_ptrs[i % lanes])
+            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | (int(os.environ.get("AL_MAC_VARIANT", "0")) << 8) | int(os.environ.get("AL_EXTRA_FLAGS", "0")), **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
         return PreparedBatch(self, plan, bufs, descs, lanes)
 

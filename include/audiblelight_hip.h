@@ -33,9 +33,10 @@ extern "C" {
 #define AL_FLAG_NO_IR_NORM 1 /* IRs are already normalised: emitter_gain := 1 (time_invariant_convolution,
                                  time_variant_convolution called directly, synthesize.py:71,277) */
 
-#define AL_FLAG_FORCE_SPLIT 4  /* opt-in: one block as two half-size transforms per workgroup (B >= 4096); slower on
-                                 MI355X (profiles/r01_split_transforms.txt), kept for boxes with less LDS headroom */
+#define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
+                               B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
+#define AL_FLAG_IR_RUN(n) (((n) & 0x7f) << 24)    /* al_ir_spectra: n consecutive partitions per workgroup (0 = 1) */
 
 #define AL_SPARSE_MAX_NJ 6          /* longest stream (in blocks) the sliding-window accumulate accepts */
 #define AL_SPARSE_MAX_PARTITIONS 24 /* most IR partitions it accepts */

@@ -43,15 +43,21 @@ def test_emu_static_event_matches_reference(emu, golden, log2_block):
     res.check_finite()
 
 
-def test_emu_split_transforms_forced_at_4096(emu, golden, monkeypatch):
-    """The split (two half-size transforms per workgroup) kernels, forced for B = 4096, incl. a moving event."""
-    monkeypatch.setenv("AL_SPLIT_FLAGS", "4")   # AL_FLAG_FORCE_SPLIT
-    a, h = golden["g1_audio"], golden["g1_irs"]
-    pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=10.0)], 4, h.shape[2], 8000, log2_block=12)
-    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1_spatial"]) < TOL
+@pytest.mark.parametrize("log2_block", [13, 14])
+def test_emu_narrow_transforms_at_large_blocks(emu, golden, monkeypatch, log2_block):
+    """B >= 8192 defaults to 32 complex values per thread; AL_FLAG_NARROW_FFT keeps the 16-value kernels reachable."""
+    monkeypatch.setenv("AL_EXTRA_FLAGS", "4")   # AL_FLAG_NARROW_FFT
+    a, h = golden["g1b_audio"], golden["g1b_irs"]
+    pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=0.5, ref_db=-50)],
+                             n_capsules=3, ir_len=h.shape[2], sample_rate=8000, log2_block=log2_block)
+    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1b_spatial"]) < TOL
+
+
+def test_emu_moving_event_wide_transforms(emu, golden):
+    """A moving event (envelope-weighted signal spectra) through the 32-values-per-thread kernels (B = 8192)."""
     a, h = golden["g3b_audio"], golden["g3b_irs"]
     spec = planning.EventSpec(n_samples=len(a), n_emitters=5, snr=12.0, is_moving=True, duration=len(a) / 8000)
-    pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=12)
+    pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=13)
     assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"]) < TOL
 
 

@@ -223,6 +223,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (pmc or {}).get(dominant),
+                     # HBM rate on the bytes actually moved (PMC traffic / live duration): what the kernel is up against
+                     "traffic_rate": ((pmc or {}).get(dominant) or 0) / (kernel_ms[dominant] * 1e-3) / 1e9 or None,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                      "hbm_bytes_per_launch_pmc": pmc},
     }

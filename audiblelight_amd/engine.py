@@ -250,6 +250,43 @@ class PreparedBatch:
                             emitter_gain=b["emitter_gain"], keep=(self,))
 
 
+class CapturedScene:
+    """A prepared batch (+ optional mixdown) recorded once into a HIP graph and replayed with one launch.
+
+    Small scenes are launch-bound (seven kernels of a few microseconds each); replaying a graph removes the
+    per-kernel launch cost.  The recorded launches read the same device tables and buffers every time, so new inputs
+    are written INTO those buffers (``PreparedBatch.bufs``) between replays.  Needs the torch/ROCm memory provider.
+    """
+
+    def __init__(self, batch: "PreparedBatch", mix: Optional["PreparedMix"] = None):
+        mem = batch.renderer.mem
+        if not hasattr(mem, "torch"):
+            raise RuntimeError("HIP graph capture needs the torch/ROCm memory provider")
+        if batch.lanes > 1:
+            raise ValueError("capture a single-lane batch")
+        torch = mem.torch
+        self.batch, self.mix = batch, mix
+        cur = torch.cuda.current_stream(mem.device)
+        side = torch.cuda.Stream(device=mem.device)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):  # one eager pass off the default stream, as capture requires
+            self._enqueue()
+        cur.wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self._enqueue()
+
+    def _enqueue(self):
+        self.batch.run()
+        if self.mix is not None:
+            self.mix.run()
+
+    def replay(self):
+        """Enqueue the whole scene on the current stream; returns (RenderResult, scene buffer or None)."""
+        self.graph.replay()
+        return self.batch.result(), (self.mix.scene if self.mix is not None else None)
+
+
 class PreparedMix:
     def __init__(self, renderer: Renderer, mix: MixPlan, desc: _hip.AlMix, scene, ambience, keep, zero_first=False):
         self.renderer, self.mix, self.desc, self.scene, self.ambience, self.keep = renderer, mix, desc, scene, ambience, keep

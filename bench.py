@@ -123,11 +123,14 @@ def main():
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
-    ap.add_argument("--cpu-events", type=int, default=6, help="events timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-events", type=int, default=16, help="events timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, metavar="N",
                     help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64)")
     ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
                     help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate)")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches; the per-stage "
+                         "times then come from a separate eager pass")
     ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
     args = ap.parse_args()
 
@@ -163,7 +166,12 @@ def main():
     stages = list(batch.STAGES) + ["al_mixdown"]
     chunked = len(batch.descs) > 1
 
+    captured = engine.CapturedScene(batch, mix) if args.graph else None
+
     def step(events=None):
+        if captured is not None and events is None:
+            captured.replay()
+            return
         if chunked:
             batch.run()
             mix.run()
@@ -191,10 +199,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(None if chunked else ev[k])
+        step(None if (chunked or captured is not None) else ev[k])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     barrier()
+    if captured is not None:  # per-stage durations from an eager pass outside the timed region
+        for k in range(args.steps):
+            step(ev[k])
+        torch.cuda.synchronize()
     if world > 1:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -219,7 +231,8 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
-                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events, "lanes": args.lanes},
+                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events, "lanes": args.lanes,
+                   "hip_graph": bool(args.graph)},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
                      "traffic": (pmc or {}).get(dominant),

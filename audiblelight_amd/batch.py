@@ -68,7 +68,8 @@ class BatchDriver:
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
         self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
-        self._pool = ThreadPoolExecutor(max_workers=max(2, min(8, (os.cpu_count() or 2))))
+        workers = int(os.environ.get("AL_COPY_THREADS", "0")) or max(2, min(16, (os.cpu_count() or 2)))
+        self._pool = ThreadPoolExecutor(max_workers=workers)
 
     def _parallel_copy(self, dst, src) -> None:
         """dst.copy_(src) split over the worker threads (a single thread moves ~8 GB/s, a scene's IRs are ~0.8 GB)."""

@@ -177,19 +177,35 @@ class Scene:
         with open(path) as fh:
             return cls.from_dict(json.load(fh), clips, irs)
 
-    def generate(self, output_dir=None, audio: bool = True, audio_fname: str = "audio_out") -> Dict[str, np.ndarray]:
-        """Render every event and mix the scene (core.py:1789-1874, audio branch); writes float32 WAV
-        files ``<audio_fname>_<mic>.wav`` when ``output_dir`` is given."""
-        from . import synthesize
+    def generate(self, output_dir=None, audio: bool = True, metadata_json: bool = True, metadata_dcase: bool = False,
+                 audio_fname: str = "audio_out", metadata_fname: str = "metadata_out", video: bool = False,
+                 video_fname: str = "video_out") -> Dict[str, np.ndarray]:
+        """Render every event and mix the scene, with the reference's argument list (core.py:1789-1874).
 
-        synthesize.render_audio_for_all_scene_events(self)
-        synthesize.generate_scene_audio_from_events(self)
-        if output_dir is not None and audio:
-            import os
+        ``audio``: render on the GPU and, when ``output_dir`` is given, write float32 WAV files
+        ``<audio_fname>_<mic>.wav`` ((T, C) interleaved like soundfile.write(audio.T), core.py:1840-1847).
+        ``metadata_json``: write ``<metadata_fname>.json`` (``to_dict``) when ``output_dir`` is given.
+        ``metadata_dcase`` / ``video`` belong to host-side subsystems that are out of scope here; asking
+        for them raises instead of silently skipping.
+        """
+        if metadata_dcase or video:
+            raise NotImplementedError("DCASE metadata and video output are host-side features of the reference "
+                                      "(synthesize.py:742-878, core.py:1866) and are not part of this path")
+        import os
 
-            from scipy.io import wavfile
-
+        if output_dir is not None:
             os.makedirs(output_dir, exist_ok=True)
-            for mic, buf in self.audio.items():
-                wavfile.write(os.path.join(output_dir, f"{audio_fname}_{mic}.wav"), self.sample_rate, buf.T)
+        if audio:
+            from . import synthesize
+
+            synthesize.render_audio_for_all_scene_events(self)
+            synthesize.generate_scene_audio_from_events(self)
+            if output_dir is not None:
+                from scipy.io import wavfile
+
+                stem = os.path.splitext(str(audio_fname))[0]
+                for mic, buf in self.audio.items():
+                    wavfile.write(os.path.join(output_dir, f"{stem}_{mic}.wav"), self.sample_rate, buf.T)
+        if metadata_json and output_dir is not None:
+            self.to_json(os.path.join(output_dir, os.path.splitext(str(metadata_fname))[0] + ".json"))
         return self.audio

@@ -259,3 +259,20 @@ def test_scene_json_round_trip(golden, tmp_path):
     again = core.Scene.from_json(path, clips={a: e._raw for a, e in scene.events.items()}, irs=dict(scene.state.irs))
     assert again.to_dict() == scene.to_dict()
     np.testing.assert_array_equal(again.generate()["mic000"], first)
+
+
+def test_scene_generate_argument_list(golden, tmp_path):
+    """Scene.generate takes the reference's arguments (core.py:1789-1799): WAV per microphone + metadata JSON on disk;
+    the host-side outputs that are out of scope raise."""
+    from scipy.io import wavfile
+
+    scene = build_g8_scene(golden, with_ambience=False)
+    out = scene.generate(output_dir=str(tmp_path), audio_fname="mix.wav", metadata_fname="meta")
+    sr, data = wavfile.read(str(tmp_path / "mix_mic000.wav"))
+    assert sr == scene.sample_rate and data.dtype == np.float32
+    np.testing.assert_array_equal(data.T, out["mic000"])
+    assert (tmp_path / "meta.json").exists()
+    with pytest.raises(NotImplementedError):
+        scene.generate(metadata_dcase=True)
+    with pytest.raises(NotImplementedError):
+        scene.generate(video=True)

@@ -53,6 +53,16 @@ def test_emu_narrow_transforms_at_large_blocks(emu, golden, monkeypatch, log2_bl
     assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1b_spatial"]) < TOL
 
 
+@pytest.mark.parametrize("log2_block", [10, 13])
+def test_emu_runs_of_blocks_per_workgroup(emu, golden, monkeypatch, log2_block):
+    """AL_FLAG_SYNTH_RUN / AL_FLAG_IR_RUN: several output blocks / IR partitions per workgroup (loop + prefetch)."""
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str((3 << 16) | (2 << 24)))
+    a, h = golden["g1_audio"], golden["g1_irs"]
+    pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=10.0)], 4, h.shape[2], 8000,
+                             log2_block=log2_block)
+    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1_spatial"]) < TOL
+
+
 def test_emu_moving_event_wide_transforms(emu, golden):
     """A moving event (envelope-weighted signal spectra) through the 32-values-per-thread kernels (B = 8192)."""
     a, h = golden["g3b_audio"], golden["g3b_irs"]

@@ -114,3 +114,15 @@ def test_block_size_choice():
     assert planning.choose_log2_block(96000, 192000) == 13
     assert planning.choose_log2_block(1000, 6000) == 10
     assert planning.choose_log2_block(5000, 3000) == 12
+
+
+def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
+    """bench.py's cpu_baseline (the oracle timed on host cores) on a shrunken cfg2 and cfg3 scene: keys and sanity."""
+    import bench
+    from audiblelight_amd import synthetic
+
+    for name, kw in (("cfg2", dict(scale=0.02)), ("cfg3", dict(scale=0.02, E=2))):
+        sc = synthetic.make_scene(name, **kw)
+        out = bench.cpu_baseline(sc, 2)
+        assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "scene-seconds/s"
+        assert out["value"] > 0 and "events" in out["sample"] and out["cpu_model"]

@@ -143,7 +143,11 @@ def main():
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend)
 
     from audiblelight_amd import engine, plan as planning, synthetic
 
@@ -208,7 +212,7 @@ def main():
             step(ev[k])
         torch.cuda.synchronize()
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     batch.result().check_finite()

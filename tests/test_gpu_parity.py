@@ -194,3 +194,34 @@ def test_full_size_properties(gpu, planning, name):
         a0, b0 = planning.event_slot(sc.starts[e], sc.ends[e], sc.sr, mix.n_samples)
         want[a0:b0] += (res.raw_spatial(e)[c].astype(np.float64) * scales[e])[: b0 - a0]
     assert rel_rms(scene[c], want) < 1e-6
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_batches_vs_oracle(gpu, planning, seed, monkeypatch):
+    """Seeded random batches (static / moving / zero-emitter events, ragged lengths, every block size, runs of blocks
+    per workgroup on or off, odd capsule counts) against the float64 oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    log2_block = int(rng.integers(10, 15))
+    if seed % 3 == 1:
+        monkeypatch.setenv("AL_EXTRA_FLAGS", str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)))
+    elif seed % 3 == 2:
+        monkeypatch.setenv("AL_EXTRA_FLAGS", "4")
+    sr, C = 16000, int(rng.integers(1, 8))
+    L = int(rng.integers(1, 3 << log2_block))
+    specs, clips, irs, col = [], [], [], 0
+    for _ in range(int(rng.integers(1, 5))):
+        kind = rng.choice(["static", "static", "moving", "dry"])
+        n_audio = int(rng.integers(600, 5 << log2_block)) if kind == "moving" else int(rng.integers(1, 5 << log2_block))
+        n_emit = {"static": 1, "dry": 0, "moving": int(rng.integers(2, 7))}[kind]
+        a = rng.standard_normal(n_audio).astype(np.float32)
+        clips.append(a / np.abs(a).max())
+        irs.append((rng.standard_normal((C, n_emit, L)) * np.exp(-np.arange(L) / max(L / 6, 1))).astype(np.float32))
+        specs.append(planning.EventSpec(n_samples=n_audio, n_emitters=n_emit, snr=float(rng.uniform(5, 30)), emitter0=col,
+                                        is_moving=n_emit > 1, duration=n_audio / sr))
+        col += n_emit
+    pl = planning.plan_batch(specs, C, L, sr, log2_block=log2_block)
+    res = gpu.render(pl, clips, np.concatenate(irs, axis=1))
+    res.check_finite()
+    for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
+        want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)
+        assert_close(res.spatial_audio(i), want["spatial"])

@@ -21,8 +21,8 @@ pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "audibleligh
 @pytest.fixture()
 def reference_synthesize():
     """Import the reference's synthesize module with stand-ins for the third-party packages absent here
-    (same recipe as tests/golden/make_golden.py); everything is removed from sys.modules afterwards."""
-    before = set(sys.modules)
+    (same recipe as tests/golden/make_golden.py); the stand-ins and the reference package are removed from sys.modules afterwards."""
+    stubbed = []
     for name in ["librosa", "librosa.util", "librosa.effects", "soundfile", "trimesh", "trimesh.visual", "loguru", "deepdiff",
                  "pedalboard", "pysofaconventions", "rlr_audio_propagation", "rtree", "pyroomacoustics", "gdown", "h5py",
                  "cv2", "pyvista", "netCDF4", "vtk"]:
@@ -30,6 +30,7 @@ def reference_synthesize():
             __import__(name)
         except Exception:
             sys.modules[name] = MagicMock()
+            stubbed.append(name)
     real_version = importlib.metadata.version
     importlib.metadata.version = lambda n: "0.1.2" if n == "audiblelight" else real_version(n)
     sys.path.insert(0, REF)
@@ -39,8 +40,8 @@ def reference_synthesize():
     finally:
         importlib.metadata.version = real_version
         sys.path.remove(REF)
-        for name in set(sys.modules) - before:
-            del sys.modules[name]
+        for name in stubbed + [m for m in sys.modules if m == "audiblelight" or m.startswith("audiblelight.")]:
+            sys.modules.pop(name, None)
 
 
 def test_install_rebinds_what_scene_generate_imports(reference_synthesize, golden):

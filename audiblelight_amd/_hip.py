@@ -17,6 +17,9 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
+FLAG_NARROW_FFT = 4
+# bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
+DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (0xff << 16) | (0x7f << 24)
 
 # numpy mirrors of al_event / al_stream (the tables are built on the host and copied to HBM)
 EVENT_DTYPE = np.dtype([
@@ -69,6 +72,7 @@ SYMBOLS = {
     "al_emitter_gains": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_signal_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
+    "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_stats": (ct.c_int, [ct.POINTER(AlBatch), _S]),

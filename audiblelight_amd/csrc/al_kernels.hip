@@ -646,50 +646,90 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream) {
   return check_error(al::launch_signal_spectra(b, (hipStream_t)stream), "k_signal_spectra");
 }
 
+// Which instantiations al_spectral_mac launches for a batch.  Static code = 1000000*KSPLIT + 10000*KT + 100*PT + VB of
+// k_spectral_mac<KT,PT,VB,KSPLIT>; moving code = 100*NJW + PT of k_spectral_mac_moving<NJW,PT,1> (0: not launched).
+static void pick_mac(const al_batch *b, int32_t *static_code, int32_t *moving_code) {
+  const int variant = (b->flags >> 8) & 15;
+  const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
+  const int bins = 1 << b->log2_block;
+  int code;
+  if (variant == 11) code = 1121202;
+  else if (variant == 12) code = 1081202;
+  else if (variant == 13) code = 1121201;
+  else if (variant == 14) code = 1061202;
+  else if (variant == 15) code = 1241201;
+  else if (variant == 1) code = 121201;
+  else if (variant == 2) code = 121202;  // k-tiles looped inside the thread
+  else if (variant == 3) code = 81202;
+  else if (variant == 4) code = 241202;
+  else if (variant == 5) code = 81201;
+  else if (variant == 6) code = 241201;
+  else if (wide_k && wide_p && bins >= 512) code = 1121202;  // fastest on cfg2 (profiles/r01_mac_variants.txt)
+  else if (wide_k) code = 240401;
+  else if (wide_p) code = 81201;
+  else code = 80401;
+  *static_code = code;
+  // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
+  *moving_code = 0;
+  if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS)
+    *moving_code = 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
+}
+
+int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code) {
+  if (int rc = check_batch(b)) return rc;
+  if (!static_code || !moving_code) return fail(AL_E_BADARG, "null output");
+  pick_mac(b, static_code, moving_code);
+  return AL_OK;
+}
+
 int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->n_emitters <= 0) return AL_OK;
   // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers.
   // flags bits 8..11 select an experimental variant (0 = default).
-  const int variant = (b->flags >> 8) & 15;
-  const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
+  int32_t code, moving;
+  pick_mac(b, &code, &moving);
   const int bins = 1 << b->log2_block;
 #define AL_MAC(KT_, PT_, VB_) \
-  hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \
-                     (hipStream_t)stream, *b)
+  case 10000 * KT_ + 100 * PT_ + VB_: \
+    hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \
+                       (hipStream_t)stream, *b); \
+    break
 #define AL_MAC_KS(KT_, PT_, VB_) \
-  hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_, true>), \
-                     dim3(bins / (256 * VB_), b->n_capsules * ((b->max_blocks + KT_ - 1) / KT_), b->n_events), dim3(256), 0, \
-                     (hipStream_t)stream, *b)
-  if (variant == 11) AL_MAC_KS(12, 12, 2);
-  else if (variant == 12) AL_MAC_KS(8, 12, 2);
-  else if (variant == 13) AL_MAC_KS(12, 12, 1);
-  else if (variant == 14) AL_MAC_KS(6, 12, 2);
-  else if (variant == 15) AL_MAC_KS(24, 12, 1);
-  else if (variant == 1) AL_MAC(12, 12, 1);
-  else if (variant == 2) AL_MAC(12, 12, 2);  // k-tiles looped inside the thread
-  else if (variant == 3) AL_MAC(8, 12, 2);
-  else if (variant == 4) AL_MAC(24, 12, 2);
-  else if (variant == 5) AL_MAC(8, 12, 1);
-  else if (variant == 6) AL_MAC(24, 12, 1);
-  else if (wide_k && wide_p && bins >= 512) AL_MAC_KS(12, 12, 2);  // fastest on cfg2 (profiles/r01_mac_variants.txt)
-  else if (wide_k) AL_MAC(24, 4, 1);
-  else if (wide_p) AL_MAC(8, 12, 1);
-  else AL_MAC(8, 4, 1);
+  case 1000000 + 10000 * KT_ + 100 * PT_ + VB_: \
+    hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_, true>), \
+                       dim3(bins / (256 * VB_), b->n_capsules * ((b->max_blocks + KT_ - 1) / KT_), b->n_events), dim3(256), 0, \
+                       (hipStream_t)stream, *b); \
+    break
+  switch (code) {
+    AL_MAC_KS(12, 12, 2);
+    AL_MAC_KS(8, 12, 2);
+    AL_MAC_KS(12, 12, 1);
+    AL_MAC_KS(6, 12, 2);
+    AL_MAC_KS(24, 12, 1);
+    AL_MAC(12, 12, 1);
+    AL_MAC(12, 12, 2);
+    AL_MAC(8, 12, 2);
+    AL_MAC(24, 12, 2);
+    AL_MAC(8, 12, 1);
+    AL_MAC(24, 12, 1);
+    AL_MAC(24, 4, 1);
+    AL_MAC(8, 4, 1);
+    default: return fail(AL_E_UNSUPPORTED, "unknown spectral MAC variant");
+  }
 #undef AL_MAC
 #undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
-  // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
-  if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS) {
+  if (moving) {
     const dim3 grid(bins / 256, b->n_capsules, b->n_events);
-    if (b->n_partitions <= 12)
+    if (moving % 100 == 12)
       hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, 12, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b);
     else
       hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, AL_SPARSE_MAX_PARTITIONS, 1>), grid, dim3(256), 0,
                          (hipStream_t)stream, *b);
     return check_launch("k_spectral_mac_moving");
   }
-  return check_launch("k_spectral_mac");
+  return AL_OK;
 }
 
 int al_block_synthesis(const al_batch *b, al_stream_t stream) {

@@ -39,12 +39,14 @@ def init_process_group(backend: Optional[str] = None):
     return dist
 
 
-def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, device=None) -> Optional[Dict[int, np.ndarray]]:
+def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, device=None, to_host: bool = True):
     """Collect per-scene (C, T) float32 buffers on rank ``dst``.
 
     ``local`` maps scene index -> torch tensor (device or CPU) or ndarray owned by this rank under
-    ``shard_indices``.  Buffers may differ in shape between scenes: shapes travel first (tiny all_gather),
-    then each round of the round-robin is one ``gather`` of equally padded tensors.
+    ``shard_indices``.  Buffers may differ in shape between scenes: shapes travel first (one tiny all_gather),
+    then every scene moves with one point-to-point send at its exact size (no padding to the round's maximum);
+    with RCCL each peer's send uses its own xGMI link into the root.  ``to_host=False`` leaves the collected
+    buffers on the root's device (torch tensors) instead of copying each one to a numpy array.
     """
     import torch
     import torch.distributed as dist
@@ -55,32 +57,42 @@ def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, devic
 
     def as_tensor(x):
         t = torch.from_numpy(np.ascontiguousarray(x)) if isinstance(x, np.ndarray) else x
-        return t.to(dev, dtype=torch.float32)
+        return t.to(dev, dtype=torch.float32).contiguous()
 
     mine = shard_indices(n_items, rank, world)
-    rounds = -(-n_items // world)
+    rounds = max(-(-n_items // world), 1)
     shapes = torch.zeros((rounds, 2), dtype=torch.int64, device=dev)
     for r, idx in enumerate(mine):
         shapes[r, 0], shapes[r, 1] = local[idx].shape[0], local[idx].shape[1]
     all_shapes = [torch.zeros_like(shapes) for _ in range(world)]
     dist.all_gather(all_shapes, shapes)
-    out: Dict[int, np.ndarray] = {}
-    for r in range(rounds):
-        sizes = [int(all_shapes[p][r, 0] * all_shapes[p][r, 1]) for p in range(world)]
-        pad = max(max(sizes), 1)
-        send = torch.zeros(pad, dtype=torch.float32, device=dev)
-        if r < len(mine):
-            flat = as_tensor(local[mine[r]]).reshape(-1)
-            send[: flat.numel()] = flat
-        recv = [torch.zeros(pad, dtype=torch.float32, device=dev) for _ in range(world)] if rank == dst else None
-        dist.gather(send, recv, dst=dst)
-        if rank == dst:
-            for p in range(world):
-                idx = r * world + p
-                if idx < n_items:
-                    c, t = int(all_shapes[p][r, 0]), int(all_shapes[p][r, 1])
-                    out[idx] = recv[p][: c * t].reshape(c, t).cpu().numpy()
-    return out if rank == dst else None
+    all_shapes = [t.cpu() for t in all_shapes]
+    out: Dict[int, object] = {}
+    ops, keep = [], []
+    if rank == dst:
+        for idx in range(n_items):
+            owner, r = idx % world, idx // world
+            c, t = int(all_shapes[owner][r, 0]), int(all_shapes[owner][r, 1])
+            if owner == dst:
+                out[idx] = as_tensor(local[idx]).reshape(c, t)
+            else:
+                out[idx] = torch.empty((c, t), dtype=torch.float32, device=dev)
+                if c * t:
+                    ops.append(dist.P2POp(dist.irecv, out[idx].view(-1), owner))
+    else:
+        for idx in mine:
+            flat = as_tensor(local[idx]).reshape(-1)
+            keep.append(flat)
+            if flat.numel():
+                ops.append(dist.P2POp(dist.isend, flat, dst))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    if rank != dst:
+        return None
+    if not to_host:
+        return out
+    return {i: v.cpu().numpy() for i, v in out.items()}
 
 
 def render_scenes(n_scenes: int, render_fn: Callable[[int], "object"], gather: bool = True, dst: int = 0):
@@ -101,8 +113,11 @@ def render_scenes(n_scenes: int, render_fn: Callable[[int], "object"], gather: b
 # ----------------------------------------------------------------------------- one scene, capsules sharded
 def capsule_slice(n_capsules: int, rank: int, world_size: int) -> slice:
     """Contiguous capsule rows owned by ``rank`` (IR bytes dominate and are capsule-separable)."""
-    per = -(-n_capsules // world_size)
-    return slice(min(rank * per, n_capsules), min((rank + 1) * per, n_capsules))
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    base, rem = divmod(n_capsules, world_size)   # balanced: the first `rem` ranks own one row more
+    lo = rank * base + min(rank, rem)
+    return slice(lo, lo + base + (1 if rank < rem else 0))
 
 
 def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_capsules: int, sample_rate: float,
@@ -121,6 +136,11 @@ def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_
 
     from . import plan as planning
 
+    if dist.is_initialized() and dist.get_world_size() > total_capsules:
+        # every rank would have to join the collectives with an empty batch; refuse up front on ALL ranks instead
+        raise ValueError(f"capsule sharding needs world_size <= capsules ({dist.get_world_size()} > {total_capsules})")
+    if irs_local.shape[0] == 0:
+        raise ValueError("this rank owns no capsule rows")
     pl = planning.plan_batch(specs, irs_local.shape[0], irs_local.shape[2], sample_rate, log2_block=log2_block)
     batch = renderer.prepare(pl, clips, irs_local)
     lib, stream = renderer.lib, renderer.mem.stream()

@@ -16,6 +16,14 @@ from . import _hip
 from .plan import BatchPlan, MixPlan
 
 
+def _debug_flags() -> int:
+    """Experimental kernel switches from the environment (AL_MAC_VARIANT, AL_EXTRA_FLAGS), masked to the bits that
+    select code paths with identical results; bit 0 (AL_FLAG_NO_IR_NORM) changes results and is never taken from it."""
+    variant = int(os.environ.get("AL_MAC_VARIANT", "0")) & 15
+    extra = int(os.environ.get("AL_EXTRA_FLAGS", "0")) & _hip.DEBUG_FLAG_MASK
+    return (variant << 8) | extra
+
+
 # ----------------------------------------------------------------------------- memory providers
 class TorchMemory:
     """HBM through torch (ROCm).  Raises if no GPU is visible: there is no CPU path."""
@@ -162,7 +170,7 @@ class Renderer:
             n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
             n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
-            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | (int(os.environ.get("AL_MAC_VARIANT", "0")) << 8) | int(os.environ.get("AL_EXTRA_FLAGS", "0")), **lane_ptrs[i % lanes])
+            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(), **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
         return PreparedBatch(self, plan, bufs, descs, lanes)
 
@@ -239,6 +247,10 @@ class PreparedBatch:
                 for name in stages:
                     lib.call(name, ct.byref(desc), stream)
         return self.result()
+
+    def stage_names(self) -> Sequence[str]:
+        """The C-ABI calls one pass of this batch makes, in order (bench.py times them one by one)."""
+        return self.STAGES
 
     def run_stage(self, name: str, chunk: int = 0) -> None:
         self.renderer.lib.call(name, ct.byref(self.descs[chunk]), self.renderer.mem.stream())

@@ -69,6 +69,7 @@ def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
         wall = time.perf_counter() - t0
     total = wall * full / work
     return dict(value=scene.duration / total, unit="scene-seconds/s", cores=workers, kind="port", cpu_model=cpu_model(),
+                extrapolated=True,
                 sample=f"{workers} events of one {scene.name} scene rendered concurrently, one oracle process each "
                        f"({wall:.1f} s wall), scaled linearly to the scene's events x IRs; mixdown not included")
 
@@ -95,6 +96,7 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
     total = t_events * full_work / max(work, 1) + t_mix * len(scene.specs) / n_events
     moving = any(sp.is_moving for sp in scene.specs)
     return dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port", cpu_model=cpu_model(),
+                extrapolated=n_events < len(scene.specs) or moving,
                 sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene"
                        + (f" with {n_irs_cap} of {scene.specs[0].n_emitters} IRs each" if moving else "")
                        + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured, "
@@ -102,22 +104,57 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
 
 
 def load_pmc_traffic(config: str, log2_block: int):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json)."""
+    """(HBM bytes per launch per stage, note) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json).
+    The table carries the hash of the kernel sources it was measured on; a table from another build is refused."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return None
+        return None, "profiles/pmc_traffic.json missing"
     try:
         table = json.load(open(path))
-        return table.get(f"{config}/log2_block={log2_block}")
-    except Exception:
-        return None
+    except Exception as exc:  # noqa: BLE001
+        return None, f"unreadable pmc_traffic.json: {exc}"
+    if table.get("source_hash") != source_hash():
+        return None, (f"pmc_traffic.json was measured on kernel sources {table.get('source_hash')}, this build is "
+                      f"{source_hash()}: re-run profiles/tools/collect_profiles.sh")
+    return table.get(f"{config}/log2_block={log2_block}"), f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {table.get('collected', '')}"
+
+
+def source_hash() -> str:
+    """Hash of the kernel sources: ties profiles/pmc_traffic.json to the build it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "audiblelight_amd", "csrc")
+    for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))):
+        h.update(name.encode())
+        h.update(open(os.path.join(csrc, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
+    touches the GPU, with the same environment torch.distributed.run would give them; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c), 0)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: about one second at cfg2)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     ap.add_argument("--log2-block", type=int, default=None)
@@ -131,19 +168,31 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches; the per-stage "
                          "times then come from a separate eager pass")
-    ap.add_argument("--gather", action="store_true", help="also time an RCCL gather of the rendered scenes to rank 0")
+    ap.add_argument("--gather", dest="gather", action="store_true", default=None,
+                    help="time an RCCL gather of the rendered scenes to rank 0 after the timed region (default: on for N > 1)")
+    ap.add_argument("--no-gather", dest="gather", action="store_false")
     args = ap.parse_args()
 
-    import torch
-
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))   # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local_rank)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
+                 f"(python bench.py --gpus N spawns them itself)")
+    if args.gather is None:
+        args.gather = world > 1
+    emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements
+
+    import torch
+
+    if not emulate:
+        torch.cuda.set_device(local_rank)
+    backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path without N GPUs
     if world > 1:
         import torch.distributed as dist
 
-        backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path on one GPU
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -152,7 +201,13 @@ def main():
     from audiblelight_amd import engine, plan as planning, synthetic
 
     scene = synthetic.make_scene(args.config, scene_index=rank, scale=args.scale)
-    r = engine.Renderer()
+    if emulate:
+        from audiblelight_amd import _hip
+        from tests import hostemu
+
+        r = engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
+    else:
+        r = engine.Renderer()   # raises without the HIP extension or a GPU: no fallback
     pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
     batch = r.prepare(pl, scene.clips, scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
     n_ev = len(scene.clips)
@@ -167,10 +222,24 @@ def main():
                          ref_db=-65, sample_rate=scene.sr)
         ambience = [_ambience_on_device(r, a, (scene.n_capsules, mix_plan.n_samples))]
     mix = r.prepare_mixdown(mix_plan, batch.result(), ambience)
-    stages = list(batch.STAGES) + ["al_mixdown"]
+    stages = list(batch.stage_names()) + ["al_mixdown"]
     chunked = len(batch.descs) > 1
 
     captured = engine.CapturedScene(batch, mix) if args.graph else None
+
+    class HostEvent:   # emulation only
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def new_event():
+        return HostEvent() if emulate else torch.cuda.Event(enable_timing=True)
+
+    def device_sync():
+        if not emulate:
+            torch.cuda.synchronize()
 
     def step(events=None):
         if captured is not None and events is None:
@@ -191,28 +260,28 @@ def main():
                 events[i][1].record()
 
     def barrier():
-        torch.cuda.synchronize()
+        device_sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        device_sync()
 
     for _ in range(args.warmup):
         step()
-    ev = [[(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in stages]
-          for _ in range(args.steps)]
+    # HIP events on the launch stream (torch's current stream is the stream every al_* call is given)
+    ev = [[(new_event(), new_event()) for _ in stages] for _ in range(args.steps)]
     barrier()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(None if (chunked or captured is not None) else ev[k])
-    torch.cuda.synchronize()
+    device_sync()
     elapsed = time.perf_counter() - t0
     barrier()
     if captured is not None:  # per-stage durations from an eager pass outside the timed region
         for k in range(args.steps):
             step(ev[k])
-        torch.cuda.synchronize()
+        device_sync()
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda" if dist.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     batch.result().check_finite()
@@ -225,23 +294,27 @@ def main():
     dominant = max(kernel_ms, key=kernel_ms.get)
     algo_bytes = scene.algorithmic_bytes()
     achieved = algo_bytes / (kernel_ms[dominant] * 1e-3) / 1e9
-    pmc = load_pmc_traffic(scene.name, pl.log2_block) if args.scale == 1.0 else None
+    ms_per_step = elapsed / args.steps * 1e3
+    pmc, pmc_note = (load_pmc_traffic(scene.name, pl.log2_block) if args.scale == 1.0 else (None, "reduced scale"))
     out = {
         "metric": METRIC,
         "value": world * args.steps * scene.duration / elapsed,
         "unit": "scene-seconds/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32", "data": "synthetic" if not emulate else "synthetic (HOST EMULATION of the kernels: not a measurement)",
         "config": {"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
                    "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events, "lanes": args.lanes,
-                   "hip_graph": bool(args.graph)},
+                   "hip_graph": bool(args.graph), "source_hash": source_hash()},
         "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS,
+                     # the same algorithmic bytes over the WHOLE step (all kernels of the scene), per GPU
+                     "path_frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                      "traffic": (pmc or {}).get(dominant),
                      # HBM rate on the bytes actually moved (PMC traffic / live duration): what the kernel is up against
                      "traffic_rate": ((pmc or {}).get(dominant) or 0) / (kernel_ms[dominant] * 1e-3) / 1e9 or None,
+                     "traffic_note": pmc_note,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                      "hbm_bytes_per_launch_pmc": pmc},
     }
@@ -261,13 +334,19 @@ def main():
     if args.gather and world > 1:
         from audiblelight_amd import distributed
 
-        torch.cuda.synchronize()
-        g0 = time.perf_counter()
         scene_t = mix.scene[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1)
-        distributed.gather_buffers({rank: scene_t}, world, dst=0)
-        torch.cuda.synchronize()
-        out["gather"] = {"ms": (time.perf_counter() - g0) * 1e3, "bytes_per_rank": int(scene_t.numel() * 4),
-                         "note": "RCCL gather of one (C, T) float32 scene per rank to rank 0 (includes the D2H on the root)"}
+        if emulate:
+            scene_t = torch.from_numpy(scene_t)
+        barrier()
+        g0 = time.perf_counter()
+        got = distributed.gather_buffers({rank: scene_t}, world, dst=0, to_host=False)
+        device_sync()
+        g_ms = (time.perf_counter() - g0) * 1e3
+        if rank == 0:
+            assert sorted(got) == list(range(world)) and all(tuple(v.shape) == tuple(scene_t.shape) for v in got.values())
+        out["gather"] = {"ms": g_ms, "bytes_per_rank": int(scene_t.numel() * 4), "backend": backend,
+                         "note": "one (C, T) float32 scene per rank collected on rank 0's device after the timed region "
+                                 "(each peer sends over its own xGMI link); not part of `value`"}
     if rank == 0:
         if world == 1 and args.cpu_events > 0:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))

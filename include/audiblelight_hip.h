@@ -155,6 +155,10 @@ int al_ir_spectra(const al_batch *b, al_stream_t stream);      /* A1 energy part
 int al_emitter_gains(const al_batch *b, al_stream_t stream);   /* A1 normalize_irs scalar per emitter */
 int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 envelope + block spectra */
 int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
+/* Which kernel instantiations al_spectral_mac launches for this batch (no launch; used by the parity tests to assert
+ * the regime they cover).  *static_code = 1000000*KSPLIT + 10000*KT + 100*PT + VB (k-tile, partition tile, bins per
+ * thread of the tile kernel); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
+int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */
 /* The two halves of al_event_levels, for a scene whose capsules are sharded over several GPUs: every rank reduces

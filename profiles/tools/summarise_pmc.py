@@ -7,9 +7,13 @@ half of the bytes of a wide coalesced streaming read (8-16 B/lane loads here), s
 """
 import collections
 import csv
+import datetime
 import json
 import os
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from bench import source_hash  # noqa: E402  (hash of the kernel sources the passes were run on)
 
 NAMES = {"k_ir_spectra": "al_ir_spectra", "k_emitter_gains": "al_emitter_gains", "k_signal_spectra": "al_signal_spectra",
          "k_spectral_mac": "al_spectral_mac", "k_block_synthesis": "al_block_synthesis", "k_event_levels": "al_event_levels",
@@ -31,6 +35,10 @@ def main():
     out = sys.argv[4] if len(sys.argv) > 4 else os.path.join(os.path.dirname(__file__), "..", "pmc_traffic.json")
     f, w = per_kernel(fetch, "FETCH_SIZE"), per_kernel(write, "WRITE_SIZE")
     table = json.load(open(out)) if os.path.exists(out) else {}
+    if table.get("source_hash") != source_hash():
+        table = {}   # entries measured on other kernel sources are stale: bench.py refuses them anyway
+    table["source_hash"] = source_hash()
+    table["collected"] = datetime.date.today().isoformat()
     table[key] = {k: int(2 * f.get(k, 0) * 1024 + w.get(k, 0) * 1024) for k in NAMES.values()}
     table[key + "/detail"] = {k: {"fetch_KiB_raw": f.get(k, 0), "write_KiB": w.get(k, 0)} for k in NAMES.values()}
     json.dump(table, open(out, "w"), indent=1)

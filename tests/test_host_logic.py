@@ -126,3 +126,31 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
         out = bench.cpu_baseline(sc, 2)
         assert out["kind"] == "port" and out["cores"] == 1 and out["unit"] == "scene-seconds/s"
         assert out["value"] > 0 and "events" in out["sample"] and out["cpu_model"]
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` starts two rank processes itself (gloo + host-emulated kernels here; RCCL + gfx950 on
+    the GPU box) and rank 0 prints ONE JSON line with n_gpus == 2, a gather figure and the per-step roofline fields."""
+    import json
+    import subprocess
+    import sys
+
+    from tests import hostemu
+
+    hostemu.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(AL_BENCH_EMULATE="1", AL_DIST_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "cfg1",
+           "--scale", "0.05", "--cpu-events", "0"]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["gather"]["bytes_per_rank"] > 0 and 0 < out["roofline"]["path_frac"] <= out["roofline"]["frac"]
+    assert "HOST EMULATION" in out["data"]
+    # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
+    bad = subprocess.run(cmd, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr

@@ -1,0 +1,22 @@
+"""Every dispatch branch of al_spectral_mac on the host-emulated kernels (B = 1024): index arithmetic of the k-tile /
+p-tile loops, KSPLIT workgroup mapping and the sliding-window kernel, every row against the oracle.  The gfx950
+build repeats these at every block size in tests/test_gpu_mac_regimes.py."""
+import pytest
+
+from audiblelight_amd import _hip, engine
+from tests import hostemu, mac_regimes as mr
+
+
+@pytest.fixture(scope="module")
+def emu():
+    return engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
+
+
+@pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
+def test_emu_static_regimes(emu, name, code, k_mult, p_mult):
+    mr.run_static_case(emu, 10, code, k_mult, p_mult, C=2)
+
+
+@pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (12.6, 624), (24.2, 0)])
+def test_emu_moving_regimes(emu, p_mult, expect):
+    mr.run_moving_case(emu, 10, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect, C=2, E=1)

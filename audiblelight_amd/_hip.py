@@ -89,6 +89,11 @@ SYMBOLS = {
     "al_pack_irs_f64": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),
     "al_noise_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_noise_irfft": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
+    "al_stft_workspace_floats": (ct.c_int64, [ct.c_int64, ct.c_int32]),
+    "al_stft": (ct.c_int, [_P, ct.c_int64, ct.c_int64, ct.c_int32, ct.c_int32, ct.c_int32, _P, _P, _S]),
+    "al_tv_stft_mac": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, _P, _S]),
+    "al_istft_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int32, ct.c_int32]),
+    "al_istft_ola": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, _P, _P, _S]),
     "al_scale_matrix_rows": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _S]),
 }
 FX_GAIN, FX_INVERT, FX_REVERSE, FX_FADE, FX_CLIP, FX_TANH, FX_BITCRUSH, FX_PREEMPH, FX_DEEMPH = range(1, 10)

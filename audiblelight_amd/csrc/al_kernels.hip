@@ -18,6 +18,7 @@
 #include "al_common.h"
 #include "al_fft.h"
 #include "al_bigfft.h"
+#include "al_stft.h"
 
 namespace al {
 
@@ -929,6 +930,81 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
   }
   hipLaunchKernelGGL(al::k_noise_unpack, g_len, dim3(256), 0, st, z, n, inv_sigma / (float)p.len, out);
   return check_launch("al_noise_irfft");
+}
+
+// ---- STFT-domain intermediates of the moving path (A7), reference signatures kept in audiblelight_amd/synthesize.py
+namespace {
+bool smooth_length(int64_t n) { return n > 0 && strip_small_factors(n) == 1; }
+constexpr int64_t MAX_GRID_ROWS = 32768;  // series per launch group (grid.y limit is 65535)
+}  // namespace
+
+int64_t al_stft_workspace_floats(int64_t series, int32_t fft_size) {
+  if (series <= 0 || fft_size <= 0) return 0;
+  const int64_t group = series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS;
+  return 2 * 2 * group * (int64_t)fft_size;  // ping-pong complex buffers for one launch group
+}
+
+int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t win_size, int32_t hop_size, float *spec,
+            float *workspace, al_stream_t stream) {
+  if (!y || !spec || !workspace || rows <= 0 || n <= 0 || win_size <= 0 || hop_size <= 0 || win_size < hop_size ||
+      fft_size < win_size)
+    return fail(AL_E_BADARG, "bad stft arguments");
+  if (!smooth_length(fft_size)) return fail(AL_E_UNSUPPORTED, "stft: fft_size must factor into 2, 3, 5, 7");
+  hipStream_t st = (hipStream_t)stream;
+  const int n_frames = 2 * (int)((n + 2 * (int64_t)hop_size - 1) / (2 * (int64_t)hop_size)) + 1;
+  const int64_t series = rows * n_frames;
+  float2 *a = reinterpret_cast<float2 *>(workspace);
+  for (int64_t s0 = 0; s0 < series; s0 += MAX_GRID_ROWS) {
+    const int g = (int)(series - s0 < MAX_GRID_ROWS ? series - s0 : MAX_GRID_ROWS);
+    float2 *b = a + (int64_t)(series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS) * fft_size;
+    const dim3 grid((unsigned)((fft_size + 255) / 256), g);
+    hipLaunchKernelGGL(al::k_stft_pack, grid, dim3(256), 0, st, y, n, n_frames, fft_size, win_size, hop_size, s0, a);
+    const float2 *z = big_fft(a, b, g, fft_size, -1, st);
+    hipLaunchKernelGGL(al::k_stft_take_half, grid, dim3(256), 0, st, z, fft_size, s0, reinterpret_cast<float2 *>(spec));
+  }
+  return check_launch("al_stft");
+}
+
+int al_tv_stft_mac(const float *s_audio, const float *s_ir, const float *w_ir, int32_t n_frames, int32_t n_frames_ir,
+                   int32_t n_freq, int32_t n_ch, int32_t n_irs, float *out, al_stream_t stream) {
+  if (!s_audio || !s_ir || !w_ir || !out || n_frames <= 0 || n_frames_ir <= 0 || n_freq <= 0 || n_ch <= 0 || n_irs <= 0 ||
+      n_frames > 65535)
+    return fail(AL_E_BADARG, "bad tv_stft_mac arguments");
+  const dim3 grid((unsigned)(((int64_t)n_freq * n_ch + 255) / 256), n_frames);
+  hipLaunchKernelGGL(al::k_tv_stft_mac, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2 *>(s_audio),
+                     reinterpret_cast<const float2 *>(s_ir), w_ir, n_frames, n_frames_ir, n_freq, n_ch, n_irs,
+                     reinterpret_cast<float2 *>(out));
+  return check_launch("k_tv_stft_mac");
+}
+
+int64_t al_istft_workspace_floats(int32_t n_frames, int32_t n_ch, int32_t fft_size) {
+  if (n_frames <= 0 || n_ch <= 0 || fft_size <= 0) return 0;
+  return 2 * 2 * (int64_t)n_frames * n_ch * fft_size;
+}
+
+int al_istft_ola(const float *spatial_stft, int32_t n_frames, int32_t n_freq, int32_t n_ch, int32_t fft_size,
+                 int32_t win_size, int32_t hop_size, float *out, float *workspace, al_stream_t stream) {
+  if (!spatial_stft || !out || !workspace || n_frames <= 0 || n_ch <= 0 || fft_size <= 0 || win_size <= 0 || hop_size <= 0)
+    return fail(AL_E_BADARG, "bad istft arguments");
+  if (n_freq != fft_size / 2 + 1) return fail(AL_E_BADARG, "istft: n_freq must be fft_size / 2 + 1");
+  if (!smooth_length(fft_size)) return fail(AL_E_UNSUPPORTED, "istft: fft_size must factor into 2, 3, 5, 7");
+  if ((int64_t)n_frames * hop_size <= win_size) return fail(AL_E_BADARG, "istft: no output samples");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t series = (int64_t)n_frames * n_ch;
+  float2 *a = reinterpret_cast<float2 *>(workspace), *b = a + series * fft_size;
+  const float2 *frames = nullptr;
+  for (int64_t s0 = 0; s0 < series; s0 += MAX_GRID_ROWS) {
+    const int g = (int)(series - s0 < MAX_GRID_ROWS ? series - s0 : MAX_GRID_ROWS);
+    const dim3 grid((unsigned)((fft_size + 255) / 256), g);
+    hipLaunchKernelGGL(al::k_istft_pack, grid, dim3(256), 0, st, reinterpret_cast<const float2 *>(spatial_stft), n_freq, n_ch,
+                       fft_size, s0, a + s0 * fft_size);
+    const float2 *z = big_fft(a + s0 * fft_size, b + s0 * fft_size, g, fft_size, +1, st);
+    frames = (z == a + s0 * fft_size) ? a : b;  // every group ends in the same buffer (same pass count)
+  }
+  const int64_t total = ((int64_t)n_frames * hop_size - win_size) * n_ch;
+  hipLaunchKernelGGL(al::k_istft_ola, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, n_frames, n_ch, fft_size,
+                     win_size, hop_size, out);
+  return check_launch("al_istft_ola");
 }
 
 int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream) {

@@ -7,7 +7,8 @@ from __future__ import annotations
 
 REPLACED = ("apply_snr", "db_to_multiplier", "time_invariant_convolution", "time_variant_convolution",
             "normalize_irs", "compute_dry_audio", "render_event_audio", "render_audio_for_all_scene_events",
-            "generate_scene_audio_from_events", "validate_scene", "generate_interpolation_matrix")
+            "generate_scene_audio_from_events", "validate_scene", "generate_interpolation_matrix", "stft",
+            "perform_time_variant_convolution", "istft_overlap_synthesis")
 
 
 def install(module=None):

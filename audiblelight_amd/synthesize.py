@@ -97,6 +97,78 @@ def time_variant_convolution(irs: np.ndarray, event, fft_size=config.FFT_SIZE, w
     return res.raw_spatial(0)[:, : int(pl.events["valid_len"][0])].astype(np.float64)
 
 
+# ----------------------------------------------------------------------------- STFT-domain helpers (A7 intermediates)
+def _complex_in(r, arr: np.ndarray):
+    """complex array -> device buffer of interleaved float32 (re, im)."""
+    return r.mem.upload(np.ascontiguousarray(arr, dtype=np.complex64).view(np.float32).reshape(-1))
+
+
+def _complex_out(r, dev, shape, like=np.complex128) -> np.ndarray:
+    n = int(np.prod(shape))
+    return r.mem.download(dev)[: 2 * n].view(np.complex64).reshape(shape).astype(like)
+
+
+def stft(y: np.ndarray, fft_size=config.FFT_SIZE, win_size=config.WIN_SIZE, hop_size=config.HOP_SIZE,
+         stft_dims_first: Optional[bool] = True) -> np.ndarray:
+    """STFT with a sin^2 window, left pad ``win - hop`` (reference synthesize.py:109-145); computed on the GPU
+    (al_stft: windowing + batched FFT).  ``y`` is (..., samples); returns (frames, freq, ...) when
+    ``stft_dims_first`` else (..., freq, frames), like the reference."""
+    y = np.asarray(y)
+    fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
+    lead, n = y.shape[:-1], y.shape[-1]
+    rows = int(np.prod(lead)) if lead else 1
+    n_frames = 2 * int(np.ceil(n / (2.0 * hop_size))) + 1
+    n_freq = fft_size // 2 + 1
+    r = get_renderer()
+    dev = r.mem.upload(np.ascontiguousarray(y, dtype=np.float32).reshape(-1))
+    spec = r.mem.empty(2 * rows * n_frames * n_freq)
+    work = r.mem.empty(r.lib.call("al_stft_workspace_floats", rows * n_frames, fft_size))
+    r.lib.call("al_stft", r.mem.ptr(dev), rows, n, fft_size, win_size, hop_size, r.mem.ptr(spec), r.mem.ptr(work), r.mem.stream())
+    r.mem.synchronize()
+    like = np.complex128 if y.dtype == np.float64 else np.complex64
+    out = _complex_out(r, spec, lead + (n_frames, n_freq), like)          # (..., frames, freq)
+    if stft_dims_first:
+        out = np.moveaxis(np.moveaxis(out, -1, 0), -1, 0)                  # (frames, freq, ...): synthesize.py:141-142
+    else:
+        out = np.swapaxes(out, -1, -2)                                     # (..., freq, frames)
+    return np.ascontiguousarray(out)
+
+
+def perform_time_variant_convolution(s_audio: np.ndarray, s_ir: np.ndarray, w_ir: np.ndarray, ir_slice_min=0,
+                                     ir_relevant_ratio_max=0.5) -> np.ndarray:
+    """Convolve a bank of cross-faded IR spectrograms with an audio spectrogram (reference synthesize.py:184-252):
+    ``out[i,f,c] = sum_k S[i-k,f] sum_l W[i-k,l] H[k,f,c,l]`` on the GPU (al_tv_stft_mac).  ``ir_slice_min`` /
+    ``ir_relevant_ratio_max`` only steer a copy optimisation in the reference (zero-weight IRs are dropped, which does
+    not change the sum) and are accepted for signature compatibility."""
+    n_frames_ir, n_freq, n_ch, n_irs = s_ir.shape
+    n_frames = min(s_audio.shape[0], w_ir.shape[0])
+    r = get_renderer()
+    sa, si = _complex_in(r, s_audio), _complex_in(r, s_ir)
+    w = r.mem.upload(np.ascontiguousarray(w_ir, dtype=np.float32).reshape(-1))
+    out = r.mem.empty(2 * n_frames * n_freq * n_ch)
+    r.lib.call("al_tv_stft_mac", r.mem.ptr(sa), r.mem.ptr(si), r.mem.ptr(w), n_frames, n_frames_ir, n_freq, n_ch, n_irs,
+               r.mem.ptr(out), r.mem.stream())
+    r.mem.synchronize()
+    return _complex_out(r, out, (n_frames, n_freq, n_ch))
+
+
+def istft_overlap_synthesis(spatial_stft: np.ndarray, fft_size=config.FFT_SIZE, win_size=config.WIN_SIZE,
+                            hop_size=config.HOP_SIZE) -> np.ndarray:
+    """Inverse FFT of every frame + overlap-add synthesis -> (n_frames*hop - win, channels) (reference
+    synthesize.py:255-274), on the GPU (al_istft_ola)."""
+    n_frames, n_freq, n_ch = spatial_stft.shape
+    fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
+    r = get_renderer()
+    spec = _complex_in(r, spatial_stft)
+    n_out = n_frames * hop_size - win_size
+    out = r.mem.empty(max(n_out, 1) * n_ch)
+    work = r.mem.empty(r.lib.call("al_istft_workspace_floats", n_frames, n_ch, fft_size))
+    r.lib.call("al_istft_ola", r.mem.ptr(spec), n_frames, n_freq, n_ch, fft_size, win_size, hop_size, r.mem.ptr(out),
+               r.mem.ptr(work), r.mem.stream())
+    r.mem.synchronize()
+    return r.mem.download(out)[: n_out * n_ch].reshape(n_out, n_ch).astype(np.float64)
+
+
 def normalize_irs(irs: np.ndarray) -> np.ndarray:
     """Divide by the mean (axis -2) of the L2 norms (axis -1) (reference synthesize.py:404-428).
 
@@ -114,8 +186,9 @@ def normalize_irs(irs: np.ndarray) -> np.ndarray:
     e = e + tiny(e)
     scale = np.repeat(1.0 / e.mean(axis=1), rows).astype(np.float32)
     s_dev = r.mem.upload(scale)
-    for i in range(flat.shape[0]):
-        r.lib.call("al_scale_rows", r.mem.ptr(dev) + 4 * i * cols, cols, r.mem.ptr(s_dev) + 4 * i, r.mem.stream())
+    for r0 in range(0, flat.shape[0], 65535):  # one launch per 65535 rows (grid.y limit)
+        nr = min(65535, flat.shape[0] - r0)
+        r.lib.call("al_scale_matrix_rows", r.mem.ptr(dev) + 4 * r0 * cols, nr, cols, r.mem.ptr(s_dev) + 4 * r0, r.mem.stream())
     out = r.mem.download(dev)[: flat.size].reshape(arr.shape)
     return out.astype(arr.dtype) if np.issubdtype(arr.dtype, np.floating) else out.astype(np.float64)
 

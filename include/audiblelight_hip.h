@@ -217,6 +217,25 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
 /* x[r, :] *= scale[r]: per-channel peak normalisation (ambience.py:211-214) after al_row_stats. */
 int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream);
 
+/* ---- STFT-domain intermediates of the moving-source path (A7).  The render path evaluates the same result in the
+ * envelope form (al_signal_spectra / al_spectral_mac); these three give the reference's public helper functions of the
+ * same names a device implementation with the reference's array layouts (C order, complex64 as interleaved floats).
+ * fft_size must factor into 2, 3, 5, 7. */
+/* stft (synthesize.py:109-145): y (rows, n) float32 -> spec (rows, n_frames, fft_size/2+1) complex64,
+ * n_frames = 2*ceil(n / (2*hop)) + 1, window sin^2(pi t / win), left pad win-hop, rfft norm="backward". */
+int64_t al_stft_workspace_floats(int64_t series /* rows * n_frames */, int32_t fft_size);
+int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t win_size, int32_t hop_size, float *spec,
+            float *workspace, al_stream_t stream);
+/* perform_time_variant_convolution (synthesize.py:184-252): s_audio (F_a, n_freq), s_ir (F_ir, n_freq, n_ch, n_irs)
+ * complex64, w_ir (F_w, n_irs) float32 -> out (n_frames, n_freq, n_ch) complex64, n_frames = min(F_a, F_w) <= 65535. */
+int al_tv_stft_mac(const float *s_audio, const float *s_ir, const float *w_ir, int32_t n_frames, int32_t n_frames_ir,
+                   int32_t n_freq, int32_t n_ch, int32_t n_irs, float *out, al_stream_t stream);
+/* istft_overlap_synthesis (synthesize.py:255-274): spatial_stft (n_frames, n_freq, n_ch) complex64 -> out
+ * (n_frames*hop - win, n_ch) float32: irfft(n=fft_size, norm="forward"), overlap-add at i*hop, slice [win, n_frames*hop). */
+int64_t al_istft_workspace_floats(int32_t n_frames, int32_t n_ch, int32_t fft_size);
+int al_istft_ola(const float *spatial_stft, int32_t n_frames, int32_t n_freq, int32_t n_ch, int32_t fft_size,
+                 int32_t win_size, int32_t hop_size, float *out, float *workspace, al_stream_t stream);
+
 /* IR ingest: WorldState.get_irs() hands out float64 (C, N, L) (worldstate.py:2183-2255); this
  * converts to the float32 layout al_batch wants (row pitch `dst_pitch` >= L, multiple of 4, pad zeroed) on the device,
  * so the host never casts 1.6 GB per scene.  rows = C * N. */

@@ -6,7 +6,8 @@
  * convolution of a mono clip with every capsule IR) followed by pad_or_truncate_audio to the
  * clip length (audiblelight/utils.py:667-688, called at synthesize.py:590).  It shares no code
  * and no algorithm (no FFT) with either the numpy oracle or the HIP path, so it is an independent
- * witness for small cases.  Parity status: pinned through tests/test_oracle_golden.py (golden G1).
+ * witness for small cases.  Parity status: pinned -- tests/test_oracle_golden.py::test_c_direct_form_witness
+ * holds it to the reference goldens G1 / G1b (full convolution + truncation) and G8 (mixdown) through oracle/conv_direct.py.
  *
  *   y[c][t] = sum_m ir[c][m] * audio[t - m],   0 <= t < n_out
  */

@@ -216,6 +216,33 @@ def main():
     path = os.path.join(HERE, "reference_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+    stft_vectors(syn)
+
+
+def stft_vectors(syn):
+    """G10: the STFT-domain intermediates of the moving path (synthesize.py:109-274) on a small case of its own
+    (separate seed and file, so reference_vectors.npz is untouched): stft of clip and IRs (both axis conventions),
+    perform_time_variant_convolution, istft_overlap_synthesis."""
+    rng = np.random.default_rng(20261003)
+    sr, n_ir = 8000, 3
+    a = make_clip(rng, 2000)
+    h = make_irs(rng, 2, n_ir, 600)
+    ev = FakeEvent("g10", a, n_ir, snr=10.0, sr=sr, is_moving=True)
+    s_a = syn.stft(a.astype(np.float64))
+    s_h = syn.stft(h)
+    s_h_last = syn.stft(h, stft_dims_first=False)
+    w = syn.generate_interpolation_matrix(np.linspace(0, ev.duration, n_ir), sr, 128)
+    y = syn.perform_time_variant_convolution(s_a, s_h, w)
+    x = syn.istft_overlap_synthesis(y, 512, 256, 128)
+    # a second parameter set: fft 256 / win 128 / hop 64 on a 1-D signal
+    s_b = syn.stft(a[:777].astype(np.float64), 256, 128, 64)
+    x_b = syn.istft_overlap_synthesis(s_b[:, :, None], 256, 128, 64)
+    out = dict(g10_audio=a, g10_irs=h.astype(np.float32), g10_w=w, g10_stft_audio=s_a.astype(np.complex64),
+               g10_stft_irs=s_h.astype(np.complex64), g10_stft_irs_dims_last=s_h_last.astype(np.complex64),
+               g10_tv=y.astype(np.complex64), g10_istft=x, g10_stft_b=s_b.astype(np.complex64), g10_istft_b=x_b)
+    path = os.path.join(HERE, "reference_stft_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
 
 
 if __name__ == "__main__":

@@ -32,6 +32,7 @@ test_scene_with_device_ambience = scenarios.test_scene_with_device_ambience
 test_two_microphones_with_different_capsule_counts = scenarios.test_two_microphones_with_different_capsule_counts
 test_scene_json_round_trip = scenarios.test_scene_json_round_trip
 test_scene_generate_argument_list = scenarios.test_scene_generate_argument_list
+test_stft_helpers_match_reference = scenarios.test_stft_helpers_match_reference
 
 
 def test_large_noise_lengths_statistics():

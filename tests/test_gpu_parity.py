@@ -225,3 +225,18 @@ def test_random_batches_vs_oracle(gpu, planning, seed, monkeypatch):
     for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
         want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)
         assert_close(res.spatial_audio(i), want["spatial"])
+
+
+def test_static_vs_direct_form_c_witness(gpu, planning):
+    """The HIP convolution against oracle/conv_direct.c: a time-domain float64 sum in plain C that shares no FFT, no
+    numpy and no code with the other oracle (ragged lengths, IR longer than one block, 3 capsules)."""
+    from oracle import conv_direct as cd
+
+    rng = np.random.default_rng(77)
+    a = rng.standard_normal(3001).astype(np.float32)
+    h = (rng.standard_normal((3, 1, 2500)) * np.exp(-np.arange(2500) / 400.0)).astype(np.float32)
+    pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=9.0)], 3, 2500, 16000, log2_block=10)
+    res = gpu.render(pl, [a], h)
+    gain = orc.emitter_gains(h.astype(np.float64))[0]
+    want = cd.conv_direct(a, h[:, 0].astype(np.float64) * gain, len(a))
+    assert_close(res.raw_spatial(0), want)

@@ -276,3 +276,36 @@ def test_scene_generate_argument_list(golden, tmp_path):
         scene.generate(metadata_dcase=True)
     with pytest.raises(NotImplementedError):
         scene.generate(video=True)
+
+
+def test_stft_helpers_match_reference():
+    """stft / perform_time_variant_convolution / istft_overlap_synthesis with the reference's signatures
+    (synthesize.py:109-145,184-274), device kernels behind them, against the reference's own outputs (G10)."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_stft_vectors.npz"))
+    a, h = z["g10_audio"], z["g10_irs"]
+
+    def close(got, want, tol=2e-5):
+        assert got.shape == want.shape
+        assert np.abs(got - want).max() <= tol * np.abs(want).max()
+
+    s_a = syn.stft(a.astype(np.float64))
+    assert s_a.dtype == np.complex128 and s_a.flags.c_contiguous
+    close(s_a, z["g10_stft_audio"])
+    s_h = syn.stft(h)
+    close(s_h, z["g10_stft_irs"])
+    close(syn.stft(h, stft_dims_first=False), z["g10_stft_irs_dims_last"])
+    close(syn.stft(a[:777], 256, 128, 64), z["g10_stft_b"])
+    y = syn.perform_time_variant_convolution(z["g10_stft_audio"], z["g10_stft_irs"], z["g10_w"])
+    close(y, z["g10_tv"])
+    x = syn.istft_overlap_synthesis(z["g10_tv"], 512, 256, 128)
+    assert rel_rms(x, z["g10_istft"]) < TOL
+    assert rel_rms(syn.istft_overlap_synthesis(z["g10_stft_b"][:, :, None], 256, 128, 64), z["g10_istft_b"]) < TOL
+    # the chain of the three equals time_variant_convolution's envelope-form render of the same event
+    ev = core.Event("mv", a, 8000, snr=10.0, n_emitters=3)
+    tv = syn.time_variant_convolution(h.astype(np.float64), ev)
+    chain = syn.istft_overlap_synthesis(syn.perform_time_variant_convolution(s_a, s_h, z["g10_w"])).T
+    assert rel_rms(tv[:, : chain.shape[1]], chain[:, : tv.shape[1]]) < TOL
+    with pytest.raises(Exception, match="fft_size must factor"):
+        syn.stft(a, 2 * 11 * 13, 256, 128)

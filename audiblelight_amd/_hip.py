@@ -43,7 +43,7 @@ class AlBatch(ct.Structure):
         ("events", ct.c_void_p), ("streams", ct.c_void_p),
         ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),
         ("yspec", ct.c_void_p), ("spatial", ct.c_void_p), ("partials", ct.c_void_p), ("event_stats", ct.c_void_p),
-        ("event_scale", ct.c_void_p),
+        ("event_scale", ct.c_void_p), ("clip_scale", ct.c_void_p),
     ]
 
 
@@ -80,13 +80,17 @@ SYMBOLS = {
     "al_render_batch": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_mixdown": (ct.c_int, [ct.POINTER(AlMix), _S]),
     "al_scale_rows": (ct.c_int, [_P, ct.c_int64, _P, _S]),
+    "al_clip_scales": (ct.c_int, [ct.POINTER(AlBatch), _P, _P, _S]),
+    "al_peak_scale": (ct.c_int, [_P, ct.c_int64, ct.c_float, _P, _S]),
     "al_axpy": (ct.c_int, [_P, _P, _P, ct.c_int64, _S]),
     "al_row_stats": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _P, _S]),
     "al_row_stats_partials": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_fx_apply": (ct.c_int, [ct.c_int, _P, _P, ct.c_int64, _P, _P, _S]),
     "al_fx_frame_shuffle": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _P, ct.c_int32, _S]),
+    "al_encode_frames": (ct.c_int, [_P, ct.c_int32, ct.c_int64, ct.c_int32, _P, _S]),
     "al_wrap_copy": (ct.c_int, [_P, ct.c_int64, _P, ct.c_int64, _S]),
     "al_pack_irs_f64": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),
+    "al_pack_irs_f32": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),
     "al_noise_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_noise_irfft": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
     "al_stft_workspace_floats": (ct.c_int64, [ct.c_int64, ct.c_int32]),
@@ -96,6 +100,7 @@ SYMBOLS = {
     "al_istft_ola": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, _P, _P, _S]),
     "al_scale_matrix_rows": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, _S]),
 }
+FRAMES_F32, FRAMES_PCM16 = 0, 1
 FX_GAIN, FX_INVERT, FX_REVERSE, FX_FADE, FX_CLIP, FX_TANH, FX_BITCRUSH, FX_PREEMPH, FX_DEEMPH = range(1, 10)
 FADE_SHAPES = {"linear": 0, "exponential": 1, "logarithmic": 2, "quarter_sine": 3, "half_sine": 4, "none": 5}
 

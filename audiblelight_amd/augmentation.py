@@ -50,13 +50,15 @@ def _positive(x, cast=float):
 
 
 class DeviceClip:
-    """A mono clip resident in HBM plus its length; FX ping-pong between two buffers."""
+    """A mono clip resident in HBM plus its length; FX ping-pong between two buffers.  A whole FX chain and the peak
+    normalisation run on ONE DeviceClip: one upload, N kernel launches, at most one download."""
 
     def __init__(self, renderer, host: np.ndarray):
         self.r = renderer
         self.n = int(host.shape[-1])
         self.buf = renderer.mem.upload(np.ascontiguousarray(host, dtype=np.float32))
         self.alt = None
+        self.uploads, self.downloads = 1, 0   # PCIe crossings of the samples (tests assert the chain stays in HBM)
 
     def other(self, n: Optional[int] = None):
         n = self.n if n is None else n
@@ -70,7 +72,16 @@ class DeviceClip:
             self.n = n
 
     def host(self) -> np.ndarray:
+        self.downloads += 1
         return self.r.mem.download(self.buf)[: self.n].astype(np.float32)
+
+    def peak_normalize(self) -> None:
+        """``a / max(|a| + tiny(a))`` (event.py:535-536): the peak is reduced into a DEVICE scalar and applied from it
+        (al_peak_scale + al_scale_rows), nothing crosses PCIe."""
+        r = self.r
+        scale = r.mem.empty(1)
+        r.lib.call("al_peak_scale", r.mem.ptr(self.buf), self.n, ct.c_float(1.0), r.mem.ptr(scale), r.mem.stream())
+        r.lib.call("al_scale_rows", r.mem.ptr(self.buf), self.n, r.mem.ptr(scale), r.mem.stream())
 
 
 def _fx(clip: DeviceClip, op: int, p0: float = 0.0, iparams=None, out_of_place: bool = False) -> None:
@@ -86,11 +97,32 @@ def _fx(clip: DeviceClip, op: int, p0: float = 0.0, iparams=None, out_of_place: 
 
 def peak_normalize(audio: np.ndarray) -> np.ndarray:
     """``a / max(|a| + tiny(a))`` (event.py:535-536) with the peak reduced and the scale applied on the GPU."""
-    r = _renderer()
-    clip = DeviceClip(r, audio)
-    stats = r.mem.download(r.row_stats(clip.buf, 1, clip.n)).reshape(-1, 4)
-    _fx(clip, _hip.FX_GAIN, float(1.0 / (np.float32(stats[0, 1]) + tiny(np.float32(0)))))
+    clip = DeviceClip(_renderer(), audio)
+    clip.peak_normalize()
     return clip.host()
+
+
+def run_chain(clip: DeviceClip, augmentations, normalize: bool = True) -> DeviceClip:
+    """``for aug: a = aug(a)`` then the peak normalisation (event.py:529-536), entirely on one device-resident clip.
+    Every augmentation keeps its own pad/truncate(wrap)-to-input-length contract (augmentation.py:117-123)."""
+    for aug in augmentations:
+        aug.process_device(clip)
+    if normalize:
+        clip.peak_normalize()
+    return clip
+
+
+def fold_scalars(augmentations) -> Optional[float]:
+    """Product of a chain of PURE scalar FX (Gain, Invert), or None when the chain has anything else.  Such a chain
+    followed by the peak normalisation is one scalar on the raw clip, ``s / (|s| max|raw| + tiny)``, which the renderer
+    evaluates on the device (al_clip_scales) and folds into the clip spectra: the FX kernels are not even launched."""
+    s = 1.0
+    for aug in augmentations:
+        k = getattr(aug, "scalar", None)
+        if k is None:
+            return None
+        s *= float(np.float32(k))
+    return s
 
 
 class Augmentation:
@@ -105,18 +137,22 @@ class Augmentation:
     def apply_device(self, clip: DeviceClip) -> None:
         return None
 
+    def process_device(self, clip: DeviceClip) -> None:
+        """The FX plus the wrap-pad / truncate back to the input length, on a clip that stays in HBM."""
+        n_in = clip.n
+        self.apply_device(clip)
+        if clip.n != n_in:
+            r = clip.r
+            dst = clip.other(n_in)
+            r.lib.call("al_wrap_copy", r.mem.ptr(clip.buf), clip.n, r.mem.ptr(dst), n_in, r.mem.stream())
+            clip.swap(n_in)
+
     def process(self, input_array: np.ndarray) -> np.ndarray:
         arr = np.asarray(input_array)
         if arr.ndim == 2:
             return np.stack([self.process(row) for row in arr])
         clip = DeviceClip(_renderer(), arr)
-        n_in = clip.n
-        self.apply_device(clip)
-        if clip.n != n_in:  # wrap-pad or truncate back to the input length
-            r = clip.r
-            dst = clip.other(n_in)
-            r.lib.call("al_wrap_copy", r.mem.ptr(clip.buf), clip.n, r.mem.ptr(dst), n_in, r.mem.stream())
-            clip.swap(n_in)
+        self.process_device(clip)
         return clip.host().astype(arr.dtype if np.issubdtype(arr.dtype, np.floating) else np.float32)
 
     def __call__(self, input_array: np.ndarray) -> np.ndarray:
@@ -161,11 +197,17 @@ class Gain(EventAugmentation):
     def linear(self) -> float:
         return float(10.0 ** (self.gain_db / 20.0))
 
+    @property
+    def scalar(self) -> float:   # pure scalar FX: foldable (fold_scalars)
+        return self.linear
+
     def apply_device(self, clip):
         _fx(clip, _hip.FX_GAIN, self.linear)
 
 
 class Invert(EventAugmentation):
+    scalar = -1.0
+
     def apply_device(self, clip):
         _fx(clip, _hip.FX_INVERT)
 
@@ -305,8 +347,7 @@ class TimeWarp(EventAugmentation):
         dst = clip.other(max(n_out, clip.n))
         r.lib.call("al_fx_frame_shuffle", r.mem.ptr(clip.buf), r.mem.ptr(dst), n_out, stride, row_len,
                    r.mem.ptr(table), len(rows), r.mem.stream())
-        r.mem.synchronize()
-        clip.swap(n_out)
+        clip.swap(n_out)   # `table` may go: the allocator orders its reuse behind the launch (same stream)
 
 
 class TimeWarpSilence(TimeWarp):

@@ -17,13 +17,12 @@ import os
 import queue
 import threading
 import time
-from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass, field
 from typing import Callable, Iterable, List, Optional, Sequence
 
 import numpy as np
 
-from . import engine
+from . import _hip, engine
 from . import plan as planning
 
 
@@ -31,7 +30,7 @@ from . import plan as planning
 class SceneJob:
     """One microphone of one scene, described by arrays already in host memory."""
     specs: Sequence[planning.EventSpec]
-    clips: Sequence[np.ndarray]
+    clips: Sequence                 # float32 arrays or engine.ClipSource (device-resident / folded-FX clips)
     irs: np.ndarray                 # (C, N_total, L) float32 or float64 (WorldState.get_irs() layout)
     starts: Sequence[float]
     ends: Sequence[float]
@@ -49,39 +48,41 @@ class BatchReport:
     h2d_bytes: int = 0
     d2h_bytes: int = 0
     files: List[str] = field(default_factory=list)
+    skipped: List[str] = field(default_factory=list)     # scenes left alone because their output exists
+    latencies: dict = field(default_factory=dict)        # scene name -> seconds from staging to written / delivered
 
     @property
     def scene_seconds_per_second(self) -> float:
         return self.scene_seconds / self.wall_s if self.wall_s > 0 else 0.0
 
 
-class BatchDriver:
-    """Pipelined rendering of a stream of SceneJobs on one GPU."""
+SUBTYPES = {"PCM_16": (_hip.FRAMES_PCM16, np.int16), "FLOAT": (_hip.FRAMES_F32, np.float32)}
 
-    def __init__(self, renderer: Optional[engine.Renderer] = None, depth: int = 2):
+
+class BatchDriver:
+    """Pipelined rendering of a stream of SceneJobs on one GPU.
+
+    Staging (profiles/r02_h2d_probe.txt): the caller's IR tensor goes to HBM straight from where it lies -- the runtime
+    moves pageable memory at PCIe rate (56 GB/s), an extra pass through page-locked staging only adds host time; float64
+    and odd row pitches are fixed up by a device kernel.  Clips (6 % of the bytes) are packed into a reused page-locked
+    buffer.  The scene leaves as the file payload: ``al_encode_frames`` interleaves (and, for PCM_16, quantises) on the
+    device, the download stream copies that into page-locked memory and a writer thread puts it on disk.
+    """
+
+    def __init__(self, renderer: Optional[engine.Renderer] = None, depth: int = 2, subtype: str = "PCM_16"):
         self.r = renderer or engine.Renderer()
         if not hasattr(self.r.mem, "torch"):
             raise RuntimeError("BatchDriver needs the torch/ROCm memory provider")
+        if subtype not in SUBTYPES:
+            raise ValueError(f"subtype must be one of {sorted(SUBTYPES)}")
         self.torch = self.r.mem.torch
         self.depth = max(1, depth)
+        self.subtype = subtype
         dev = self.r.mem.device
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
         self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
-        workers = int(os.environ.get("AL_COPY_THREADS", "0")) or max(2, min(16, (os.cpu_count() or 2)))
-        self._pool = ThreadPoolExecutor(max_workers=workers)
-
-    def _parallel_copy(self, dst, src) -> None:
-        """dst.copy_(src) split over the worker threads (a single thread moves ~8 GB/s, a scene's IRs are ~0.8 GB)."""
-        n = dst.numel()
-        parts = self._pool._max_workers
-        step = -(-n // parts)
-        if n < (1 << 22):
-            dst.copy_(src)
-            return
-        futs = [self._pool.submit(lambda a, b: dst[a:b].copy_(src[a:b]), i, min(i + step, n)) for i in range(0, n, step)]
-        for f in futs:
-            f.result()
+        self._slot_ready = {}   # slot -> H2D event of the scene that last used the slot's pinned clip buffer
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
         key = (tag, dtype, int(numel))
@@ -90,7 +91,7 @@ class BatchDriver:
             pool.append(self.torch.empty(int(numel), dtype=dtype).pin_memory())
         return pool[slot]
 
-    # -- stage 1: host planning + asynchronous upload on the copy stream
+    # -- stage 1: host planning + upload on the copy stream
     def _stage(self, job: SceneJob, slot: int = 0):
         torch, r = self.torch, self.r
         c, n, l = job.irs.shape
@@ -98,115 +99,236 @@ class BatchDriver:
         n_ev = len(job.clips)
         mix_plan = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n_ev,
                                          pl.events["out_off"], list(range(n_ev)), job.duration, job.sample_rate, c)
-        packed = torch.from_numpy(r.pack_audio(pl, job.clips))
-        audio_host = self._pinned_buffer("audio", packed.dtype, packed.numel(), slot)
-        audio_host.copy_(packed)
-        flat = torch.from_numpy(np.ascontiguousarray(job.irs).reshape(-1))
-        irs_host = self._pinned_buffer("irs", flat.dtype, flat.numel(), slot)
-        self._parallel_copy(irs_host, flat)   # host memcpy into page-locked staging: the host-side cost of the boundary
-        lp = (l + 3) // 4 * 4
+        prev = self._slot_ready.get(slot)
+        if prev is not None:
+            prev.synchronize()   # the slot's pinned clip buffer may still be the source of an H2D copy in flight
+        audio_host = self._pinned_buffer("audio", torch.float32, pl.audio_floats, slot)
+        r.pack_audio(pl, job.clips, out=audio_host.numpy())
         with torch.cuda.stream(self.copy_stream):
-            irs_raw = irs_host.to(r.mem.device, non_blocking=True)
-            if job.irs.dtype == np.float64 or lp != l:
-                if job.irs.dtype != np.float64:
-                    irs_raw = irs_raw.double()
-                irs_dev = torch.empty(c * n * lp, dtype=torch.float32, device=r.mem.device)
-                import ctypes as ct
-                r.lib.call("al_pack_irs_f64", irs_raw.data_ptr(), irs_dev.data_ptr(), c * n, l, lp,
-                           ct.c_void_p(self.copy_stream.cuda_stream))
-            else:
-                irs_dev = irs_raw
             audio_dev = audio_host.to(r.mem.device, non_blocking=True)
+            for off, clip in zip(pl.audio_offsets, job.clips):   # clips already in HBM (device FX chain)
+                src = engine.as_clip_source(clip)
+                if src.host is None:
+                    audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]
+            irs_dev, strides = r.upload_irs(job.irs)             # straight from the caller's memory
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        h2d = irs_host.numel() * irs_host.element_size() + audio_host.numel() * 4
-        return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=(n * lp, lp), audio=audio_dev, ready=ready,
-                    keep=(audio_host, irs_host, irs_raw), h2d=h2d, slot=slot)
+        self._slot_ready[slot] = ready
+        h2d = job.irs.nbytes + pl.audio_floats * 4
+        return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=strides, audio=audio_dev, ready=ready,
+                    h2d=h2d, slot=slot, t0=time.perf_counter())
 
     # -- stage 2: kernels on the current (compute) stream
     def _render(self, st):
         torch, r = self.torch, self.r
         cur = torch.cuda.current_stream(r.mem.device)
         cur.wait_event(st["ready"])
+        # tensors made on the copy stream are used here: tell the allocator, or it may hand them out again too early
+        st["irs"].record_stream(cur)
+        st["audio"].record_stream(cur)
         batch = r.prepare(st["plan"], st["job"].clips, st["irs"], st["strides"], audio_dev=st["audio"])
         res = batch.run()
         scene = r.prepare_mixdown(st["mix"], res, st["job"].ambience).run()
-        done = torch.cuda.Event()
-        done.record(cur)
-        st.update(result=res, scene=scene, done=done, batch=batch)
+        st.update(result=res, scene=scene, batch=batch)
         return st
 
-    # -- stage 3: D2H on the download stream into pinned memory
-    def _download(self, st):
-        torch = self.torch
+    # -- stage 3: encode on the device, D2H on the download stream into pinned memory
+    def _download(self, st, want_frames: bool, want_scene: bool, subtype: str):
+        import ctypes as ct
+
+        torch, r = self.torch, self.r
         c, t = st["mix"].n_capsules, st["mix"].n_samples
-        host = self._pinned_buffer("scene", torch.float32, c * t, st.get("slot", 0))
+        cur = torch.cuda.current_stream(r.mem.device)
+        fmt, np_dtype = SUBTYPES[subtype]
+        frames_dev = None
+        if want_frames:
+            tdt = torch.int16 if np_dtype == np.int16 else torch.float32
+            frames_dev = torch.empty(c * t, dtype=tdt, device=r.mem.device)
+            r.lib.call("al_encode_frames", st["scene"].data_ptr(), c, t, fmt, frames_dev.data_ptr(),
+                       ct.c_void_p(cur.cuda_stream))
+        done = torch.cuda.Event()
+        done.record(cur)
         with torch.cuda.stream(self.down_stream):
-            self.down_stream.wait_event(st["done"])
-            host.copy_(st["scene"][: c * t], non_blocking=True)
+            self.down_stream.wait_event(done)
+            if want_frames:
+                frames_dev.record_stream(self.down_stream)
+                host = self._pinned_buffer("frames", frames_dev.dtype, c * t, st["slot"])
+                host.copy_(frames_dev, non_blocking=True)
+                st["frames"] = host
+            if want_scene:
+                st["scene"].record_stream(self.down_stream)
+                host = self._pinned_buffer("scene", torch.float32, c * t, st["slot"])
+                host.copy_(st["scene"][: c * t], non_blocking=True)
+                st["host"] = host
             landed = torch.cuda.Event()
             landed.record(self.down_stream)
-        st.update(host=host, landed=landed)
+        st.update(landed=landed)
         return st
 
     def run(self, jobs: Iterable[SceneJob], output_dir: Optional[str] = None,
-            on_scene: Optional[Callable[[str, np.ndarray], None]] = None, check_finite: bool = True) -> BatchReport:
-        """Render all jobs; per scene either write ``<output_dir>/<name>.wav`` (float32, (T, C) interleaved like
-        soundfile.write(audio.T) in core.py:1840-1847) or hand the (C, T) array to ``on_scene``."""
+            on_scene: Optional[Callable[[str, np.ndarray], None]] = None, check_finite: bool = True,
+            subtype: Optional[str] = None, skip_existing: bool = False,
+            path_of: Optional[Callable[[SceneJob], str]] = None) -> BatchReport:
+        """Render all jobs.  With ``output_dir`` every scene is written to ``<output_dir>/<name>.wav`` (or
+        ``path_of(job)``): (T, C) interleaved frames like ``soundfile.write(audio.T, sr)`` (core.py:1840-1847), subtype
+        ``PCM_16`` (soundfile's default for WAV) or ``FLOAT``; ``skip_existing`` leaves scenes whose file exists alone
+        (scripts/generate/benchmark.py:54-55).  ``on_scene(name, array)`` receives a (C, T) float32 array of its own
+        (a copy: the page-locked download buffers are reused a few scenes later).  A failure in the writer thread
+        (non-finite audio, disk error, callback error) stops the run and is re-raised here."""
+        subtype = subtype or self.subtype
+        if subtype not in SUBTYPES:
+            raise ValueError(f"subtype must be one of {sorted(SUBTYPES)}")
         rep = BatchReport()
         sink: "queue.Queue" = queue.Queue(maxsize=self.depth + 1)
+        failure: List[BaseException] = []
+        want_frames, want_scene = output_dir is not None, on_scene is not None
+        if path_of is None:
+            path_of = lambda job: os.path.join(output_dir, f"{job.name}.wav")  # noqa: E731
+
+        def write_one(st):
+            st["landed"].synchronize()
+            if check_finite:
+                st["result"].check_finite()
+            c, t = st["mix"].n_capsules, st["mix"].n_samples
+            if want_frames:
+                from scipy.io import wavfile
+
+                path = path_of(st["job"])
+                os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+                wavfile.write(path, int(st["job"].sample_rate), st["frames"].numpy().reshape(t, c))
+                rep.files.append(path)
+                rep.d2h_bytes += st["frames"].numel() * st["frames"].element_size()
+            if want_scene:
+                on_scene(st["job"].name, st["host"].numpy().reshape(c, t).copy())
+                rep.d2h_bytes += c * t * 4
+            rep.latencies[st["job"].name] = time.perf_counter() - st["t0"]
 
         def writer():
             while True:
                 item = sink.get()
                 if item is None:
                     return
-                st = item
-                st["landed"].synchronize()
-                if check_finite:
-                    st["result"].check_finite()
-                c, t = st["mix"].n_capsules, st["mix"].n_samples
-                arr = st["host"].numpy().reshape(c, t)
-                if output_dir is not None:
-                    from scipy.io import wavfile
-
-                    path = os.path.join(output_dir, f"{st['job'].name}.wav")
-                    wavfile.write(path, st["job"].sample_rate, arr.T)
-                    rep.files.append(path)
-                if on_scene is not None:
-                    on_scene(st["job"].name, arr)
-                rep.d2h_bytes += arr.nbytes
+                if failure:
+                    continue          # keep draining so the producer never blocks on a full queue
+                try:
+                    write_one(item)
+                except BaseException as exc:  # noqa: BLE001  (re-raised by run())
+                    failure.append(exc)
 
         if output_dir is not None:
             os.makedirs(output_dir, exist_ok=True)
         th = threading.Thread(target=writer, daemon=True)
         th.start()
         t0 = time.perf_counter()
-        staged = None
-        it = iter(jobs)
-        nxt = next(it, None)
-        n_slots = self.depth + 2   # staging slots in flight: being filled, being rendered, being written
+        n_slots = self.depth + 3   # live at once: being written, `depth` queued, being rendered, being staged
         index = 0
-        if nxt is not None:
-            staged = self._stage(nxt, index % n_slots)
-        while staged is not None:
-            cur = staged
-            nxt = next(it, None)
-            index += 1
-            # upload of scene i+1 overlaps the render of scene i; a slot is reused only after its scene was written
-            while nxt is not None and sink.qsize() > self.depth:
-                time.sleep(0.0005)
+
+        def next_job(it):
+            for job in it:
+                if skip_existing and want_frames and os.path.exists(path_of(job)):
+                    rep.skipped.append(job.name)
+                    continue
+                return job
+            return None
+
+        try:
+            it = iter(jobs)
+            nxt = next_job(it)
             staged = self._stage(nxt, index % n_slots) if nxt is not None else None
-            st = self._download(self._render(cur))
-            rep.n_scenes += 1
-            rep.scene_seconds += cur["job"].duration
-            rep.h2d_bytes += cur["h2d"]
-            sink.put(st)
-        sink.put(None)
-        th.join()
+            while staged is not None and not failure:
+                cur = staged
+                st = self._download(self._render(cur), want_frames, want_scene, subtype)   # enqueue only (asynchronous)
+                nxt = next_job(it)
+                index += 1
+                # the upload of scene i+1 (host-blocking, PCIe-bound) runs while the GPU renders scene i
+                staged = self._stage(nxt, index % n_slots) if nxt is not None else None
+                rep.n_scenes += 1
+                rep.scene_seconds += cur["job"].duration
+                rep.h2d_bytes += cur["h2d"]
+                sink.put(st)          # blocks while the writer is `depth` + 1 scenes behind: back-pressure
+        finally:
+            sink.put(None)
+            th.join()
         self.torch.cuda.synchronize(self.r.mem.device)
         rep.wall_s = time.perf_counter() - t0
+        if failure:
+            raise failure[0]
         return rep
+
+
+# ----------------------------------------------------------------------------- dataset loop
+def scene_jobs(scene, name: str, renderer: Optional[engine.Renderer] = None) -> List[SceneJob]:
+    """One SceneJob per microphone of a Scene-like object (the attribute list of SURVEY.md 8a A15): what
+    ``render_audio_for_all_scene_events`` + ``generate_scene_audio_from_events`` read from it
+    (synthesize.py:613-677, 314-401), packaged for the pipelined driver."""
+    from . import synthesize
+
+    synthesize.validate_scene(scene)
+    jobs = []
+    n_scene = round(scene.duration * scene.sample_rate)
+    for mic_alias, mic_ir in scene.state.get_irs().items():
+        specs, clips, starts, ends, col = [], [], [], [], 0
+        for event in scene.events.values():
+            clip = synthesize._clip_of(event, False)
+            specs.append(synthesize._spec_of(event, clip, len(event), col, scene.ref_db))
+            clips.append(clip)
+            starts.append(event.scene_start)
+            ends.append(event.scene_end)
+            col += len(event)
+        ambience = []
+        if len(getattr(scene, "ambience", {})) > 0:
+            r = renderer or synthesize.get_renderer()
+            ambience = [synthesize._ambience_on_device(r, a, (mic_ir.shape[0], n_scene)) for a in scene.ambience.values()]
+        jobs.append(SceneJob(specs=specs, clips=clips, irs=np.asarray(mic_ir), starts=starts, ends=ends,
+                             duration=scene.duration, sample_rate=scene.sample_rate, name=f"{name}/{mic_alias}",
+                             ambience=ambience))
+    return jobs
+
+
+def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True, subtype: str = "PCM_16",
+                   audio_fname: str = "audio_out", metadata_fname: str = "metadata_out", metadata_json: bool = True,
+                   driver: Optional[BatchDriver] = None) -> BatchReport:
+    """The reference's dataset loops on the pipelined driver (scripts/generate/benchmark.py:35-82,
+    scripts/generate/generate_with_random_events.py:222-238, scripts/seld/generate_dataset.py:96-260).
+
+    ``scenes`` yields ``(name, scene)`` or ``(name, factory)`` pairs (a zero-argument factory is only called for
+    scenes that are actually rendered).  Layout, as ``make_a_scene`` leaves it: ``<output_dir>/<name>/
+    <audio_fname>_<mic>.wav`` ((T, C) frames, soundfile's default PCM_16 unless ``subtype="FLOAT"``) and
+    ``<metadata_fname>.json`` = ``scene.to_dict()`` plus ``"time"`` (seconds from staging to the file on disk).
+    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55)."""
+    import json
+
+    driver = driver or BatchDriver(subtype=subtype)
+    os.makedirs(output_dir, exist_ok=True)
+    meta = {}
+    skipped = []
+
+    def jobs():
+        for name, scene in scenes:
+            folder = os.path.join(output_dir, name)
+            if skip_existing and os.path.isdir(folder):
+                skipped.append(name)
+                continue
+            if callable(scene) and not hasattr(scene, "events"):
+                scene = scene()
+            os.makedirs(folder, exist_ok=True)
+            per_mic = scene_jobs(scene, name, driver.r)
+            meta[name] = (scene, [j.name for j in per_mic])
+            yield from per_mic
+
+    def path_of(job):
+        name, mic = job.name.rsplit("/", 1)
+        return os.path.join(output_dir, name, f"{audio_fname}_{mic}.wav")
+
+    rep = driver.run(jobs(), output_dir=output_dir, subtype=subtype, path_of=path_of)
+    rep.skipped.extend(skipped)
+    if metadata_json:
+        for name, (scene, job_names) in meta.items():
+            d = scene.to_dict() if hasattr(scene, "to_dict") else {}
+            d["time"] = max(rep.latencies.get(j, 0.0) for j in job_names)
+            with open(os.path.join(output_dir, name, f"{metadata_fname}.json"), "w") as fh:
+                json.dump(d, fh, indent=4, ensure_ascii=False)
+    return rep
 
 
 # ----------------------------------------------------------------------------- many small scenes in one launch sequence

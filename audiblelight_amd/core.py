@@ -64,25 +64,53 @@ class Event:
 
     def clear_audio(self) -> None:
         self.audio = None
+        self._last_chain = None
         self.spatial_audio = LazyAudioDict()
         self._spatial_audio_padded = LazyAudioDict()
         self._spatial_audio_dry = OrderedDict()
         self._spatial_audio_dry_padded = OrderedDict()
 
+    def _device_chain(self, normalize: bool):
+        """Raw clip -> HBM once, the whole FX chain and the peak normalisation there (augmentation.run_chain)."""
+        from . import augmentation, synthesize
+
+        device_fx = all(hasattr(a, "process_device") for a in self.augmentations)
+        if not device_fx:   # foreign callables (e.g. host pedalboard FX of the reference): run them where they live
+            out = self._raw.copy()
+            for aug in self.augmentations:
+                out = aug(out)
+            clip = augmentation.DeviceClip(synthesize.get_renderer(), out)
+            return augmentation.run_chain(clip, [], normalize)
+        clip = augmentation.DeviceClip(synthesize.get_renderer(), self._raw)
+        return augmentation.run_chain(clip, self.augmentations, normalize)
+
     def load_audio(self, ignore_cache: Optional[bool] = False, normalize: Optional[bool] = True) -> np.ndarray:
-        """Clip after the FX chain and peak normalisation (event.py:496-539); cached in ``self.audio``."""
+        """Clip after the FX chain and peak normalisation (event.py:496-539); cached in ``self.audio``.
+        One upload, the chain on the device, one download (no intermediate copies between FX)."""
         if self.is_audio_loaded and not ignore_cache:
             return self.audio
-        out = self._raw.copy()
-        for aug in self.augmentations:
-            out = aug(out)
-        if normalize:
-            from . import augmentation
-
-            out = augmentation.peak_normalize(out)
+        clip = self._device_chain(bool(normalize))
+        out = clip.host()
         valid_audio(out)
         self.audio = out
+        self._last_chain = clip
         return self.audio
+
+    def clip_source(self, ignore_cache: Optional[bool] = False):
+        """What the renderer needs of this event's clip WITHOUT bringing samples back to the host
+        (engine.ClipSource): a chain of pure scalars (Gain, Invert) + peak normalisation becomes the raw clip plus
+        one device-evaluated scalar; any other chain runs on the device and is handed over in HBM; a clip somebody
+        already loaded to the host (``self.audio``) is used as it is."""
+        from . import augmentation, engine
+
+        if self.is_audio_loaded and not ignore_cache:
+            return engine.ClipSource(host=np.ascontiguousarray(self.audio, dtype=np.float32), n=len(self.audio))
+        folded = augmentation.fold_scalars(self.augmentations)
+        if folded is not None:
+            return engine.ClipSource(host=self._raw, n=len(self._raw), prescale=folded, normalize=True)
+        clip = self._device_chain(True)
+        self._last_chain = clip
+        return engine.ClipSource(device=clip.buf, n=clip.n)
 
     def to_dict(self) -> dict:
         return dict(alias=self.alias, sample_rate=self.sample_rate, snr=self.snr, scene_start=self.scene_start,

@@ -558,16 +558,81 @@ __global__ __launch_bounds__(256) void k_frame_shuffle(const float *src, float *
   }
 }
 
+// ------------------------------------------------------------------ clip scales (A13 peak normalisation, folded FX scalars)
+// scale = s / (|s| * max|x| + tiny(float32)): peak normalisation `a / max(|a| + tiny)` (event.py:535-536) of the clip
+// s * x, where s is the product of the scalar FX in front of it (Gain, Invert); one workgroup per clip.
+__device__ __forceinline__ float peak_scale_of(const float *__restrict__ x, int64_t n, float s, float *red) {
+  float mx = 0.f, z0 = 0.f, z1 = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(x[i]));
+  block_reduce3(z0, mx, z1, red, threadIdx.x, 1024);
+  return s / (fabsf(s) * mx + 1.17549435e-38f);
+}
+
+// mode[e] 0: clip_scale[e] = prescale[e]; 1: the peak-normalising scale of clip e (events table gives offset / length)
+__global__ __launch_bounds__(1024) void k_clip_scales(al_batch b, const float *__restrict__ prescale,
+                                                      const int32_t *__restrict__ mode, float *__restrict__ out) {
+  __shared__ float red[48];
+  const int e = b.event0 + blockIdx.x;
+  const al_event ev = b.events[e];
+  const float s = prescale[e];
+  if (mode[e] == 0) {
+    if (threadIdx.x == 0) out[e] = s;
+    return;
+  }
+  const float v = peak_scale_of(b.audio + ev.audio_off, ev.len, s, red);
+  if (threadIdx.x == 0) out[e] = v;
+}
+
+__global__ __launch_bounds__(1024) void k_peak_scale(const float *__restrict__ x, int64_t n, float s, float *__restrict__ out) {
+  __shared__ float red[48];
+  const float v = peak_scale_of(x, n, s, red);
+  if (threadIdx.x == 0) *out = v;
+}
+
 __global__ __launch_bounds__(256) void k_scale_matrix_rows(float *x, int64_t cols, const float *scale) {
   const float s = scale[blockIdx.y];
   float *row = x + (int64_t)blockIdx.y * cols;  // rows = channels of an ambience: far below grid.y's limit
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cols; i += (int64_t)gridDim.x * 256) row[i] *= s;
 }
 
-__global__ __launch_bounds__(256) void k_pack_irs_f64(const double *src, float *dst, int len, int pitch) {
-  const double *row = src + (int64_t)blockIdx.x * len;   // one workgroup per row: rows = C*N may exceed grid.y's 65535
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_irs(const T *src, float *dst, int len, int pitch) {
+  const T *row = src + (int64_t)blockIdx.x * len;   // one workgroup per row: rows = C*N may exceed grid.y's 65535
   float *out = dst + (int64_t)blockIdx.x * pitch;
   for (int t = threadIdx.x; t < pitch; t += 256) out[t] = t < len ? (float)row[t] : 0.f;
+}
+
+// (C, T) float32 scene -> (T, C) interleaved frames, the layout soundfile.write(audio.T) puts on disk (core.py:1840-1847).
+// One workgroup per tile of 32 capsules x 64 samples through LDS: reads run along t, writes along c.
+template <bool PCM16>
+__global__ __launch_bounds__(256) void k_encode_frames(const float *__restrict__ scene, int n_capsules, int64_t n_samples,
+                                                       void *__restrict__ out) {
+  __shared__ float tile[32][65];
+  const int64_t t0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 32; r += 4) {
+    const int c = c0 + r + ty;
+    tile[r + ty][tx] = (c < n_capsules && t0 + tx < n_samples) ? scene[(int64_t)c * n_samples + t0 + tx] : 0.f;
+  }
+  __syncthreads();
+  const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
+#pragma unroll
+  for (int tt = 0; tt < 64; tt += 8) {
+    const int64_t t = t0 + tt + tl;
+    const int c = c0 + cl;
+    if (c < n_capsules && t < n_samples) {
+      const float x = tile[cl][tt + tl];
+      if (PCM16) {
+        // libsndfile float -> short with its default normalisation: lrint(x * 0x7FFF); saturated here (it would wrap)
+        const double q = rint((double)x * 32767.0);
+        reinterpret_cast<int16_t *>(out)[t * n_capsules + c] = (int16_t)fmin(fmax(q, -32768.0), 32767.0);
+      } else {
+        reinterpret_cast<float *>(out)[t * n_capsules + c] = x;
+      }
+    }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_wrap_copy(const float *src, int64_t m, float *dst, int64_t n) {
@@ -786,6 +851,21 @@ int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream) {
   const int64_t blocks = (n + 255) / 256;
   hipLaunchKernelGGL(al::k_scale, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
   return check_launch("k_scale");
+}
+
+int al_clip_scales(const al_batch *b, const float *prescale, const int32_t *mode, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (!prescale || !mode || !b->clip_scale) return fail(AL_E_BADARG, "clip_scales needs prescale, mode and al_batch.clip_scale");
+  if (b->n_events <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_clip_scales, dim3(b->n_events), dim3(1024), 0, (hipStream_t)stream, *b, prescale, mode,
+                     const_cast<float *>(b->clip_scale));
+  return check_launch("k_clip_scales");
+}
+
+int al_peak_scale(const float *x, int64_t n, float prescale, float *scale_out, al_stream_t stream) {
+  if (!x || !scale_out || n <= 0) return fail(AL_E_BADARG, "bad peak_scale arguments");
+  hipLaunchKernelGGL(al::k_peak_scale, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, n, prescale, scale_out);
+  return check_launch("k_peak_scale");
 }
 
 int al_axpy(float *y, const float *x, const float *a_dev, int64_t n, al_stream_t stream) {
@@ -1018,8 +1098,26 @@ int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scal
 int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream) {
   if (!src || !dst || rows <= 0 || len <= 0 || dst_pitch < len || (dst_pitch & 3) || rows > 0x7fffffff)
     return fail(AL_E_BADARG, "bad pack_irs arguments");
-  hipLaunchKernelGGL(al::k_pack_irs_f64, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst, len, dst_pitch);
-  return check_launch("k_pack_irs_f64");
+  hipLaunchKernelGGL(al::k_pack_irs<double>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst, len, dst_pitch);
+  return check_launch("k_pack_irs<double>");
+}
+
+int al_pack_irs_f32(const float *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream) {
+  if (!src || !dst || src == dst || rows <= 0 || len <= 0 || dst_pitch < len || (dst_pitch & 3) || rows > 0x7fffffff)
+    return fail(AL_E_BADARG, "bad pack_irs arguments");
+  hipLaunchKernelGGL(al::k_pack_irs<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst, len, dst_pitch);
+  return check_launch("k_pack_irs<float>");
+}
+
+int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream) {
+  if (!scene || !out || n_capsules <= 0 || n_samples <= 0 || (format != AL_FRAMES_F32 && format != AL_FRAMES_PCM16))
+    return fail(AL_E_BADARG, "bad encode_frames arguments");
+  const dim3 grid((unsigned)((n_samples + 63) / 64), (unsigned)((n_capsules + 31) / 32));
+  if (format == AL_FRAMES_PCM16)
+    hipLaunchKernelGGL((al::k_encode_frames<true>), grid, dim3(256), 0, (hipStream_t)stream, scene, n_capsules, n_samples, out);
+  else
+    hipLaunchKernelGGL((al::k_encode_frames<false>), grid, dim3(256), 0, (hipStream_t)stream, scene, n_capsules, n_samples, out);
+  return check_launch("k_encode_frames");
 }
 
 int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream) {

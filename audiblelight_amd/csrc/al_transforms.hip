@@ -105,6 +105,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_signal
   const float *a = b.audio + ev.audio_off;
   const bool moving = st.w_off >= 0 && st.w_len > 0;
   const float *w = b.wtab + (moving ? st.w_off : 0);
+  const float clip_gain = st.gain * (b.clip_scale ? b.clip_scale[st.event] : 1.f);  // A13 scale computed on the device
   const int j = st.j_lo + blockIdx.x;
   const int t0 = (j - 1) * M;  // window [(j-1)B, (j+1)B)
   const int last = ev.len - 1;
@@ -123,7 +124,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_signal
 #pragma unroll
   for (int m = 0; m < E; ++m) {
     const int t = t0 + 2 * (tid + T * m);
-    float g0 = st.gain, g1 = st.gain;
+    float g0 = clip_gain, g1 = clip_gain;
     if (moving) {  // workgroup-uniform
       g0 *= stream_envelope(w, st.w_len, b.hop, max(t, 0));
       g1 *= stream_envelope(w, st.w_len, b.hop, max(t + 1, 0));
@@ -164,7 +165,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
     float asum = 0.f, amax = 0.f, bad = 0.f;
     if (!conv) {
       // no emitters: the clip is tiled over the capsules (synthesize.py:572-577)
-      const float gain = b.streams[ev.stream0].gain;
+      const float gain = b.streams[ev.stream0].gain * (b.clip_scale ? b.clip_scale[b.event0 + blockIdx.z] : 1.f);
       const float *a = b.audio + ev.audio_off;
       for (int i = tid; i < M; i += T) {
         const int t = tbase + i;

@@ -55,10 +55,41 @@ class TorchMemory:
         return buf.data_ptr()
 
     def download(self, buf) -> np.ndarray:
-        return buf.cpu().numpy()
+        """Device buffer -> fresh ndarray.  Large buffers land in page-locked memory from torch's caching host allocator
+        (55 GB/s instead of 12 GB/s into freshly faulted pageable memory, profiles/r02_h2d_probe.txt); the array keeps
+        that block alive and the block returns to the cache when the array is dropped."""
+        if buf.numel() * buf.element_size() < (1 << 22):
+            return buf.cpu().numpy()
+        host = self.torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        self.torch.cuda.current_stream(self.device).synchronize()
+        return host.numpy()
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+
+# ----------------------------------------------------------------------------- clip hand-over
+@dataclass
+class ClipSource:
+    """One event's mono clip as the renderer takes it: in host memory or already in HBM, plus what is still to be
+    applied to it ON THE DEVICE: the product of scalar FX (Gain, Invert) and the peak normalisation of
+    ``Event.load_audio`` (event.py:529-536).  A plain ndarray means "finished clip" (prescale 1, no normalisation)."""
+    host: Optional[np.ndarray] = None
+    device: object = None          # device buffer (first ``n`` floats), used when ``host`` is None
+    n: int = 0
+    prescale: float = 1.0
+    normalize: bool = False
+
+    def __len__(self) -> int:
+        return int(self.n if self.host is None else len(self.host))
+
+
+def as_clip_source(clip) -> ClipSource:
+    if isinstance(clip, ClipSource):
+        return clip
+    arr = np.ascontiguousarray(clip, dtype=np.float32)
+    return ClipSource(host=arr, n=len(arr))
 
 
 # ----------------------------------------------------------------------------- results
@@ -113,23 +144,31 @@ class Renderer:
 
     # -- IR upload: (C, N, L) any float dtype -> float32 device tensor with 4-float aligned rows
     def upload_irs(self, irs: np.ndarray):
+        """The caller's (C, N, L) tensor goes to HBM AS IT IS (no host-side copy, cast or padding pass: the H2D copy of
+        pageable memory runs at PCIe rate, a fresh ``np.zeros`` + copy at a fifth of it, profiles/r02_h2d_probe.txt);
+        float64 (what ``WorldState.get_irs()`` returns, worldstate.py:2183-2255) and rows whose length is not a
+        multiple of 4 are converted / re-pitched by a device kernel."""
         c, n, l = irs.shape
         lp = (l + 3) // 4 * 4
-        if irs.dtype == np.float64 and n > 0 and irs.size >= (1 << 20):
-            # big float64 tensors (what WorldState.get_irs() returns): copy as they are, convert on the device
-            raw = self.mem.upload(np.ascontiguousarray(irs).reshape(-1))
-            dev = self.mem.empty(c * n * lp)
-            self.lib.call("al_pack_irs_f64", self.mem.ptr(raw), self.mem.ptr(dev), c * n, l, lp, self.mem.stream())
-            self.mem.synchronize()
-            return dev, (n * lp, lp)
-        host = np.zeros((c, max(n, 1), lp), dtype=np.float32)
-        host[:, :n, :l] = irs
-        return self.mem.upload(host.reshape(-1)), (n * lp if n else lp, lp)
+        if n == 0 or l == 0:
+            return self.mem.zeros(max(c, 1) * lp), (lp, lp)
+        if irs.dtype not in (np.float32, np.float64):
+            irs = irs.astype(np.float32)
+        raw = self.mem.upload(np.ascontiguousarray(irs).reshape(-1))
+        if irs.dtype == np.float32 and lp == l:
+            return raw, (n * lp, lp)
+        dev = self.mem.empty(c * n * lp)
+        self.lib.call("al_pack_irs_f64" if irs.dtype == np.float64 else "al_pack_irs_f32", self.mem.ptr(raw),
+                      self.mem.ptr(dev), c * n, l, lp, self.mem.stream())
+        return dev, (n * lp, lp)   # `raw` may be released: the allocator orders its reuse behind the kernel (same stream)
 
-    def pack_audio(self, plan: BatchPlan, clips: Sequence[np.ndarray]) -> np.ndarray:
-        host = np.zeros(plan.audio_floats, dtype=np.float32)
+    def pack_audio(self, plan: BatchPlan, clips: Sequence, out: Optional[np.ndarray] = None) -> np.ndarray:
+        """Host clips at their 4-float aligned offsets (device-resident clips are copied in HBM by ``prepare``)."""
+        host = np.zeros(plan.audio_floats, dtype=np.float32) if out is None else out
         for off, clip in zip(plan.audio_offsets, clips):
-            host[off: off + len(clip)] = clip
+            src = as_clip_source(clip)
+            if src.host is not None:
+                host[off: off + len(src)] = src.host
         return host
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
@@ -150,8 +189,15 @@ class Renderer:
         x_blocks = max(max(c["xspec_blocks"] for c in chunks), 1)
         y_blocks = max(max(c["yspec_blocks"] for c in chunks), 1)
         lanes = max(1, min(int(lanes), len(chunks)))
+        sources = [as_clip_source(c) for c in clips]
+        if audio_dev is None:
+            audio_dev = mem.upload(self.pack_audio(plan, sources))
+            for off, src in zip(plan.audio_offsets, sources):   # clips that are already in HBM (device FX chain): D2D
+                if src.host is None:
+                    audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]
+        fold = any(src.normalize or src.prescale != 1.0 for src in sources)
         bufs = dict(
-            audio=audio_dev if audio_dev is not None else mem.upload(self.pack_audio(plan, clips)), ir=irs,
+            audio=audio_dev, ir=irs,
             events=mem.upload(plan.events),
             streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
             wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
@@ -160,6 +206,8 @@ class Renderer:
             yspec=mem.empty(y_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
             partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
             event_scale=mem.empty(len(plan.events)))
+        if fold:
+            bufs["clip_scale"] = mem.empty(len(plan.events))
         ptrs = {k: mem.ptr(v) for k, v in bufs.items()}
         extra = [dict(hspec=mem.empty(h_blocks * B * 2), xspec=mem.empty(x_blocks * B * 2), yspec=mem.empty(y_blocks * B * 2))
                  for _ in range(lanes - 1)]
@@ -172,6 +220,12 @@ class Renderer:
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
             yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(), **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
+        if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
+            pre = mem.upload(np.array([src.prescale for src in sources], dtype=np.float32))
+            mode = mem.upload(np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32))
+            for desc in descs:
+                self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
+            bufs["_clip_tables"] = (pre, mode)
         return PreparedBatch(self, plan, bufs, descs, lanes)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
@@ -259,7 +313,11 @@ class PreparedBatch:
         b = self.bufs
         return RenderResult(plan=self.plan, memory=self.renderer.mem, lib=self.renderer.lib, spatial=b["spatial"],
                             event_scale=b["event_scale"], event_stats=b["event_stats"],
-                            emitter_gain=b["emitter_gain"], keep=(self,))
+                            emitter_gain=b["emitter_gain"],
+                            # launches on the current stream are ordered against the allocator's reuse of the spectra
+                            # workspace, so a finished single-lane batch need not be kept alive by its result (it would
+                            # pin 5-13 GB per microphone for as long as an event keeps its render); side streams do
+                            keep=(self,) if self.lanes > 1 else ())
 
 
 class CapturedScene:

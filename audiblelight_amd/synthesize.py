@@ -194,7 +194,12 @@ def normalize_irs(irs: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- event rendering
-def _clip_of(event, ignore_cache: bool) -> np.ndarray:
+def _clip_of(event, ignore_cache: bool):
+    """The event's clip for the renderer: ``engine.ClipSource`` from events that can hand it over without a host
+    round trip (core.Event.clip_source: device FX chain, folded Gain/Invert + peak normalisation), else the array
+    ``event.load_audio()`` returns (reference Events: event.py:496-539)."""
+    if hasattr(event, "clip_source"):
+        return event.clip_source(ignore_cache=ignore_cache)
     audio = event.load_audio(ignore_cache=ignore_cache, normalize=True)
     valid_audio(audio)
     return np.ascontiguousarray(audio, dtype=np.float32)
@@ -223,10 +228,10 @@ def _publish(event, mic_alias: str, res: engine.RenderResult, index: int) -> Non
         validate_shape(out.shape, (n_ch, n_samp))
         return out
 
+    # the mixdown reads the render straight from HBM for as long as THIS entry is what event.spatial_audio[mic] holds:
+    # an assignment by the user or clear_audio() replaces / drops the entry and with it the device source
+    fetch.al_device_source = (res, index)
     LazyAudioDict.__setitem__(event.spatial_audio, mic_alias, fetch)
-    if not hasattr(event, "_al_device"):
-        event._al_device = {}
-    event._al_device[mic_alias] = (res, index)
 
 
 def compute_dry_audio(event, irs: np.ndarray, event_scale: float, mic_alias: str) -> None:
@@ -330,8 +335,9 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
 def _device_source(r: engine.Renderer, event, mic_alias: str):
     """(device buffer, offset, len, rows, scale buffer, scale index) of an event's render; uploads host
     arrays that did not come from this package (scale 1)."""
-    held = getattr(event, "_al_device", {}).get(mic_alias)
-    if held is not None and isinstance(event.spatial_audio, LazyAudioDict):
+    sa = event.spatial_audio
+    held = sa.device_source(mic_alias) if isinstance(sa, LazyAudioDict) else None
+    if held is not None:
         res, idx = held
         ev = res.plan.events[idx]
         return res.spatial, int(ev["out_off"]), int(ev["len"]), res.plan.n_capsules, res.event_scale, idx

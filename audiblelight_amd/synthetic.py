@@ -30,14 +30,26 @@ class SyntheticScene:
     specs: List[EventSpec]
     starts: List[float]
     ambience_beta: object = None  # noise colour of the scene ambience (cfg5: "white"), None = no ambience
+    gain_db: object = None        # cfg5: per-event Gain(gain_db) of the [Gain, Invert] chain; `clips` are then RAW clips
+
+    def sources(self):
+        """What the renderer is given per event: finished clips, or (cfg5) the raw clip plus the folded scalar of its
+        [Gain(gain_db), Invert] chain with the peak normalisation left to the device (engine.ClipSource)."""
+        from .engine import ClipSource
+
+        if self.gain_db is None:
+            return self.clips
+        return [ClipSource(host=c, n=len(c), prescale=-float(np.float32(10.0 ** (g / 20.0))), normalize=True)
+                for c, g in zip(self.clips, self.gain_db)]
 
     def describe(self) -> str:
         sp = self.specs[0]
         kind = f"{sp.n_emitters}-IR moving" if sp.is_moving else "static"
         return (f"{self.name}: 1 scene/GPU/step, {self.n_capsules} capsules, {len(self.specs)} {kind} events, "
                 f"{self.ir_len / self.sr:g} s RIR, {len(self.clips[0]) / self.sr:g} s clips, {self.duration:g} s scene @ "
-                f"{self.sr} Hz" + (f", {self.ambience_beta} ambience + Gain/Invert FX folded into the clip gain"
-                                   if self.ambience_beta is not None else ""))
+                f"{self.sr} Hz" + (f", {self.ambience_beta} ambience" if self.ambience_beta is not None else "")
+                + (", [Gain, Invert] + peak normalisation per event evaluated on the device and folded into the clip spectra"
+                   if self.gain_db is not None else ""))
 
     @property
     def ends(self):
@@ -58,23 +70,20 @@ def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, **o
     rng = np.random.default_rng(1234 + scene_index)
     decay = np.exp(-np.arange(Lir, dtype=np.float32) / np.float32(Lir / 6.9))
     irs = np.empty((C, E * N, Lir), dtype=np.float32)
-    clips, specs, starts = [], [], []
+    clips, specs, starts, gains_db = [], [], [], []
     for e in range(E):
         a = rng.standard_normal(La, dtype=np.float32)
-        a = a / np.max(np.abs(a) + np.finfo(np.float32).tiny)
+        if not cfg.get("fx"):   # finished clip: peak-normalised as Event.load_audio leaves it (event.py:535-536)
+            a = a / np.max(np.abs(a) + np.finfo(np.float32).tiny)
         clips.append(a.astype(np.float32))
         for n in range(N):
             h = rng.standard_normal((C, Lir), dtype=np.float32) * decay
             h[np.arange(C), rng.integers(48, min(960, Lir), size=C)] += 1.0
             irs[:, e * N + n, :] = h
-        gain = 1.0
-        if cfg.get("fx"):
-            # [Gain(gain_db ~ U(-10, 10)), Invert] then peak normalisation (event.py:529-536) fold into one
-            # scalar on the already peak-normalised clip: -g / (g * 1 + tiny)
-            g = 10.0 ** (float(rng.uniform(-10, 10)) / 20.0)
-            gain = float(-g / (g + np.finfo(np.float32).tiny))
+        if cfg.get("fx"):   # raw clip + [Gain(gain_db ~ U(-10, 10)), Invert]: see SyntheticScene.sources
+            gains_db.append(float(rng.uniform(-10, 10)))
         specs.append(EventSpec(n_samples=La, n_emitters=N, snr=float(rng.uniform(5, 30)), emitter0=e * N,
-                               is_moving=N > 1, duration=La / sr, ref_db=-65.0, gain=gain))
+                               is_moving=N > 1, duration=La / sr, ref_db=-65.0))
         starts.append(float(rng.uniform(0, max(T - La / sr, 0.0))))
     return SyntheticScene(name=name, sr=sr, duration=T, n_capsules=C, ir_len=Lir, clips=clips, irs=irs, specs=specs,
-                          starts=starts, ambience_beta=cfg.get("ambience"))
+                          starts=starts, ambience_beta=cfg.get("ambience"), gain_db=gains_db if cfg.get("fx") else None)

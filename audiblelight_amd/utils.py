@@ -74,6 +74,13 @@ class LazyAudioDict(OrderedDict):
     def items(self):
         return [(k, self[k]) for k in self.keys()]
 
+    def device_source(self, key):
+        """The (RenderResult, event index) behind a value that is STILL the device-backed render, else None (the value
+        was read into a host array and possibly edited, replaced by the user, or never came from this package)."""
+        if not self.is_resident(key):
+            return None
+        return getattr(super().__getitem__(key), "al_device_source", None)
+
     def is_resident(self, key) -> bool:
         """True while the value has not been copied to the host yet."""
         return key in self and callable(super().__getitem__(key))

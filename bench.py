@@ -57,7 +57,7 @@ def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
         sp = scene.specs[i % len(scene.specs)]
         n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
         h = scene.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
-        jobs.append((scene.clips[i % len(scene.clips)], h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr))
+        jobs.append((oracle_clip(scene, i % len(scene.clips)), h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr))
         work += max(n_used, 1)
     for sp in scene.specs:
         full += max(sp.n_emitters, 1)
@@ -74,6 +74,15 @@ def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
                        f"({wall:.1f} s wall), scaled linearly to the scene's events x IRs; mixdown not included")
 
 
+def oracle_clip(scene, i):
+    """The clip the oracle convolves: cfg5's raw clips go through its [Gain, Invert] chain + peak normalisation."""
+    from oracle import synth_oracle as orc
+
+    if scene.gain_db is None:
+        return scene.clips[i]
+    return orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(scene.clips[i], scene.gain_db[i]))).astype(np.float32)
+
+
 def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
     """Time the float64 numpy/scipy oracle (kind "port") on a bounded sample of the same workload."""
     from oracle import synth_oracle as orc
@@ -84,7 +93,7 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
         sp = scene.specs[i]
         n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
         h = scene.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
-        spatials.append(orc.render_event(scene.clips[i], h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr)["spatial"])
+        spatials.append(orc.render_event(oracle_clip(scene, i), h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr)["spatial"])
         work += n_used
     for sp in scene.specs:
         full_work += max(sp.n_emitters, 1)
@@ -209,7 +218,7 @@ def main():
     else:
         r = engine.Renderer()   # raises without the HIP extension or a GPU: no fallback
     pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
-    batch = r.prepare(pl, scene.clips, scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
+    batch = r.prepare(pl, scene.sources(), scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
     n_ev = len(scene.clips)
     mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
                                      pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)

@@ -120,6 +120,9 @@ typedef struct {
   float *partials;   /* workspace: 4 floats per (event, c, k): sum|x|, max|x|, non-finite count, pad */
   double *event_stats; /* out: 4 doubles per event: sum|x|, max|x|, non-finite count, total scale */
   float *event_scale;  /* out: per event multiplier = apply_snr o db_to_multiplier (synthesize.py:594-599) */
+  const float *clip_scale; /* optional (NULL = 1): per event scalar applied to the clip on top of al_stream.gain; written on
+                              the device by al_clip_scales (peak normalisation + folded Gain/Invert, event.py:529-536), so
+                              the clip's peak never travels to the host.  Indexed globally like event_scale. */
 } al_batch;
 
 /* Mixdown of one microphone (generate_scene_audio_from_events, synthesize.py:314-401). */
@@ -173,6 +176,13 @@ int al_mixdown(const al_mix *m, al_stream_t stream);
 /* x[r, :] *= scale[r_index] for a (rows, cols) block: scales an event's spatial audio in place
  * (event.spatial_audio, synthesize.py:599,606). scale is a device pointer to ONE float. */
 int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream);
+/* A13 on the device, without a host round trip.  al_clip_scales: for every event of the batch, clip_scale[e] =
+ * prescale[e] (mode[e] == 0) or prescale[e] / (|prescale[e]| * max|clip_e| + tiny(float32)) (mode[e] == 1): the
+ * peak normalisation `a / max(|a| + tiny)` of event.py:535-536 applied to the clip prescale[e] * clip_e, i.e. behind a
+ * chain of pure scalar FX (Gain: 10^(dB/20), Invert: -1; augmentation.py:1105-1136,1557-1580).  prescale (float32[E]) and
+ * mode (int32[E]) are device arrays indexed like al_batch.events.  al_peak_scale: the same scalar for one buffer. */
+int al_clip_scales(const al_batch *b, const float *prescale, const int32_t *mode, al_stream_t stream);
+int al_peak_scale(const float *x, int64_t n, float prescale, float *scale_out, al_stream_t stream);
 /* y += a * x over n floats; a = *a_dev (ambience add, synthesize.py:350-356). */
 int al_axpy(float *y, const float *x, const float *a_dev, int64_t n, al_stream_t stream);
 /* Row statistics of a (rows, cols) float32 matrix: out[r] = {sum|x|, max|x|, non-finite count, sum x^2} (doubles). */
@@ -240,6 +250,17 @@ int al_istft_ola(const float *spatial_stft, int32_t n_frames, int32_t n_freq, in
  * converts to the float32 layout al_batch wants (row pitch `dst_pitch` >= L, multiple of 4, pad zeroed) on the device,
  * so the host never casts 1.6 GB per scene.  rows = C * N. */
 int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream);
+/* The same re-pitching for float32 IRs whose length is not a multiple of 4 (ragged listeners padded to the longest IR,
+ * worldstate.py:2236-2253): the caller's array goes to HBM as it is and is laid out on the device. */
+int al_pack_irs_f32(const float *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream);
+
+/* Output encoding for the WAV writer: (C, T) float32 scene -> (T, C) interleaved frames as
+ * soundfile.write(mic_audio.T, sr) stores them (core.py:1840-1847).  AL_FRAMES_PCM16 is soundfile's default subtype for
+ * WAV: int16 = lrint(x * 32767) (libsndfile's float->short normalisation), saturated; AL_FRAMES_F32 keeps float32.
+ * Done on the device so the D2H copy is already the file payload (half the bytes for PCM_16). */
+#define AL_FRAMES_F32 0
+#define AL_FRAMES_PCM16 1
+int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream);
 
 /* dst[t] = src[t mod m] for t < n: np.pad(..., mode="wrap") of Augmentation.process. */
 int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream);

@@ -33,6 +33,7 @@ test_two_microphones_with_different_capsule_counts = scenarios.test_two_micropho
 test_scene_json_round_trip = scenarios.test_scene_json_round_trip
 test_scene_generate_argument_list = scenarios.test_scene_generate_argument_list
 test_stft_helpers_match_reference = scenarios.test_stft_helpers_match_reference
+test_fx_chain_stays_on_device_and_scalars_fold = scenarios.test_fx_chain_stays_on_device_and_scalars_fold
 
 
 def test_large_noise_lengths_statistics():

@@ -20,7 +20,10 @@ def gpu():
 def oracle_event(sc, i):
     sp = sc.specs[i]
     h = sc.irs[:, sp.emitter0: sp.emitter0 + sp.n_emitters, :].astype(np.float64)
-    return orc.render_event(sc.clips[i] * np.float32(sp.gain), h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, sc.sr)["spatial"]
+    clip = sc.clips[i]
+    if sc.gain_db is not None:   # cfg5: raw clip -> [Gain, Invert] -> peak normalisation, as the reference chains them
+        clip = orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(clip, sc.gain_db[i])))
+    return orc.render_event(clip, h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, sc.sr)["spatial"]
 
 
 def test_cfg3_moving_sources(gpu):
@@ -54,53 +57,159 @@ def test_cfg4_scene_batch_in_one_launch(gpu):
 
 
 def test_cfg5_64ch_ambience_and_folded_fx(gpu):
-    from audiblelight_amd import ambience as amb, plan as planning, synthetic
+    """BASELINE configs[4] reduced: built from the PRODUCT's classes -- core.Event(augmentations=[Gain, Invert]),
+    amb.Ambience("white"), Scene.generate() -- and compared with the oracle's chain
+    mix(render(peak_normalise(invert(gain(raw))))) + ambience.  No FX kernel runs and no clip comes back to the host:
+    the scalar is evaluated on the device (al_clip_scales) and folded into the clip spectra."""
+    from audiblelight_amd import ambience as amb, augmentation as aug, core, synthetic
     from audiblelight_amd import synthesize as syn
 
     syn.set_renderer(gpu)
     try:
         sc = synthetic.make_scene("cfg5", scale=0.03, E=6)
-        assert sc.n_capsules == 64 and all(sp.gain < 0 for sp in sc.specs)    # Invert folded into the gain
-        pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)
-        res = gpu.render(pl, sc.clips, sc.irs)
+        assert sc.n_capsules == 64 and len(sc.gain_db) == 6
+        scene = core.Scene(sc.duration, core.StaticIRState({"em64": sc.irs}), sample_rate=sc.sr, ref_db=-65)
+        for i, (raw, sp) in enumerate(zip(sc.clips, sc.specs)):
+            scene.add_event(core.Event(f"e{i}", raw, sc.sr, snr=sp.snr, scene_start=sc.starts[i],
+                                       augmentations=[aug.Gain(sc.sr, gain_db=sc.gain_db[i]), aug.Invert(sc.sr)]))
+        scene.add_ambience(amb.Ambience(channels=64, duration=sc.duration, alias="a", noise="white", ref_db=-65, sample_rate=sc.sr))
+        got = scene.generate()["em64"]
+        assert all(ev.audio is None and getattr(ev, "_last_chain", None) is None for ev in scene.events.values())
         n = len(sc.specs)
-        mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [64] * n, pl.events["out_off"],
-                                    list(range(n)), sc.duration, sc.sr, 64)
-        a = amb.Ambience(channels=64, duration=sc.duration, alias="a", noise="white", ref_db=-65, sample_rate=sc.sr)
-        dev = syn._ambience_on_device(gpu, a, (64, mix.n_samples))
-        got = gpu.mem.download(gpu.mixdown(mix, res, [dev]))[: 64 * mix.n_samples].reshape(64, -1)
         noise = orc.ambience_noise(0, 64, sc.duration, sc.sr)
         want = orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
                              ambiences=[(noise, -65)], keep_padded=False)["scene"]
         assert rel_rms(got, want) < TOL
+        # the same through the engine-level hand-over the bench uses (ClipSource with prescale + normalize)
+        from audiblelight_amd import plan as planning
+
+        pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)
+        res = gpu.render(pl, sc.sources(), sc.irs)
+        for i in (0, n - 1):
+            assert rel_rms(res.spatial_audio(i), oracle_event(sc, i)) < TOL
     finally:
         syn.set_renderer(None)
 
 
-def test_batch_driver_matches_direct_render(gpu, tmp_path):
-    """pipelined multi-scene driver (async H2D / render / D2H + WAV writer) gives the same audio
-    as rendering each scene on its own; float64 IRs go through the device-side ingest kernel."""
+def oracle_scene(sc):
+    n = len(sc.specs)
+    return orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
+                         keep_padded=False)["scene"]
+
+
+def test_batch_driver_writes_what_the_oracle_mixes(gpu, tmp_path):
+    """the pipelined multi-scene driver (H2D / render / device-side frame encoding / D2H / WAV writer)
+    against the ORACLE's scenes: float32 frames within the parity tolerance, PCM_16 frames (soundfile's default subtype,
+    core.py:1840-1847) within one LSB of lrint(oracle * 32767); float64 IRs go through the device-side ingest kernel;
+    skip_existing leaves written scenes alone (benchmark.py:54-55)."""
     from scipy.io import wavfile
 
-    from audiblelight_amd import batch, plan as planning, synthetic
+    from audiblelight_amd import batch, synthetic
 
     scenes = [synthetic.make_scene("cfg1", scene_index=i, scale=0.5) for i in range(4)]
     jobs = [batch.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs.astype(np.float64) if i % 2 else sc.irs,
                            starts=sc.starts, ends=sc.ends, duration=sc.duration, sample_rate=sc.sr, name=f"s{i}")
             for i, sc in enumerate(scenes)]
+    want = [oracle_scene(sc) for sc in scenes]
     got = {}
-    rep = batch.BatchDriver(gpu).run(jobs, output_dir=str(tmp_path), on_scene=lambda name, arr: got.__setitem__(name, arr.copy()))
+    drv = batch.BatchDriver(gpu)
+    rep = drv.run(jobs, output_dir=str(tmp_path / "f32"), on_scene=got.__setitem__, subtype="FLOAT")
     assert rep.n_scenes == 4 and len(rep.files) == 4 and rep.scene_seconds == pytest.approx(4 * scenes[0].duration)
     for i, sc in enumerate(scenes):
-        pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)
-        res = gpu.render(pl, sc.clips, sc.irs)
-        mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [sc.n_capsules] * len(sc.clips),
-                                    pl.events["out_off"], list(range(len(sc.clips))), sc.duration, sc.sr, sc.n_capsules)
-        want = gpu.mem.download(gpu.mixdown(mix, res))[: sc.n_capsules * mix.n_samples].reshape(sc.n_capsules, -1)
-        np.testing.assert_allclose(got[f"s{i}"], want, rtol=1e-6, atol=1e-12)
-        sr, wav = wavfile.read(str(tmp_path / f"s{i}.wav"))
-        assert sr == sc.sr and wav.shape == (mix.n_samples, sc.n_capsules)
-        np.testing.assert_array_equal(wav.T, got[f"s{i}"])
+        assert rel_rms(got[f"s{i}"], want[i]) < TOL
+        sr, wav = wavfile.read(str(tmp_path / "f32" / f"s{i}.wav"))
+        assert sr == sc.sr and wav.dtype == np.float32 and wav.shape == want[i].T.shape
+        np.testing.assert_array_equal(wav.T, got[f"s{i}"])          # the file holds exactly the rendered scene
+    rep16 = drv.run(jobs, output_dir=str(tmp_path / "pcm"))           # default subtype
+    assert rep16.d2h_bytes * 2 == rep.d2h_bytes - sum(w.size * 4 for w in want)   # half the payload, no float copy
+    for i, sc in enumerate(scenes):
+        sr, wav = wavfile.read(str(tmp_path / "pcm" / f"s{i}.wav"))
+        assert wav.dtype == np.int16 and wav.shape == want[i].T.shape
+        ref = np.rint(want[i].T.astype(np.float64) * 32767.0)
+        assert np.abs(wav.astype(np.float64) - ref).max() <= 1
+        # bit-exact against the encoder's definition applied to the float32 scene the device held
+        np.testing.assert_array_equal(wav, np.clip(np.rint(got[f"s{i}"].T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16))
+    again = drv.run(jobs, output_dir=str(tmp_path / "pcm"), skip_existing=True)
+    assert again.n_scenes == 0 and sorted(again.skipped) == [f"s{i}" for i in range(4)]
+
+
+def test_batch_driver_reports_writer_failures(gpu, tmp_path):
+    """A non-finite scene or a failing callback must surface from run() (the reference raises through
+    librosa.util.valid_audio, synthesize.py:398,603), not die silently in the writer thread or hang the producer."""
+    from audiblelight_amd import batch, synthetic
+
+    scenes = [synthetic.make_scene("cfg1", scene_index=i, scale=0.25) for i in range(8)]
+    scenes[2].clips[1][100] = np.nan
+    jobs = [batch.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs, starts=sc.starts, ends=sc.ends, duration=sc.duration,
+                           sample_rate=sc.sr, name=f"s{i}") for i, sc in enumerate(scenes)]
+    with pytest.raises(ValueError, match="not finite"):
+        batch.BatchDriver(gpu, depth=1).run(jobs, output_dir=str(tmp_path))
+
+    def boom(name, arr):
+        raise RuntimeError("callback failed")
+
+    with pytest.raises(RuntimeError, match="callback failed"):
+        batch.BatchDriver(gpu, depth=1).run(jobs[3:], on_scene=boom)
+
+
+def test_render_dataset_layout_and_audio(gpu, tmp_path):
+    """The reference's dataset loop (scripts/generate/benchmark.py:35-82, generate_with_random_events.py:222-238) on the
+    pipelined driver: Scene objects in, ``<out>/<scene>/audio_out_<mic>.wav`` + ``metadata_out.json`` with "time" out;
+    audio checked against the oracle (two microphones with different capsule counts, an FX chain, an ambience);
+    a second pass skips what exists without building the scenes."""
+    import json
+
+    from scipy.io import wavfile
+
+    from audiblelight_amd import ambience as amb, augmentation as aug, batch, core
+    from audiblelight_amd import synthesize as syn
+
+    syn.set_renderer(gpu)
+    try:
+        sr, dur = 16000, 1.5
+        built = []
+
+        def make(i):
+            rng = np.random.default_rng(900 + i)
+            irs = {"mic_a": (rng.standard_normal((4, 3, 900)) * np.exp(-np.arange(900) / 200.0)).astype(np.float32),
+                   "mic_b": (rng.standard_normal((2, 3, 900)) * np.exp(-np.arange(900) / 150.0)).astype(np.float64)}
+            scene = core.Scene(dur, core.StaticIRState(irs), sample_rate=sr, ref_db=-60)
+            raws = [rng.standard_normal(n).astype(np.float32) for n in (9000, 12000, 7000)]
+            fx = [[], [aug.Gain(sr, gain_db=-3.0), aug.Invert(sr)], [aug.Fade(sr, 0.02, 0.03, "linear", "linear")]]
+            for k, raw in enumerate(raws):
+                scene.add_event(core.Event(f"e{k}", raw, sr, snr=8.0 + 3 * k, scene_start=0.1 + 0.3 * k, augmentations=fx[k]))
+            built.append(i)
+            return scene, raws, irs
+
+        made = {}
+
+        def factory(i):
+            def build():
+                made[i] = make(i)
+                return made[i][0]
+            return build
+
+        rep = batch.render_dataset(((f"scene_{i:03d}", factory(i)) for i in range(3)), str(tmp_path), subtype="FLOAT")
+        assert rep.n_scenes == 6 and built == [0, 1, 2]
+        for i in range(3):
+            scene, raws, irs = made[i]
+            clips = [orc.peak_normalise_clip(raws[0]), orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(raws[1], -3.0))),
+                     orc.peak_normalise_clip(orc.fx_fade(raws[2], sr, 0.02, 0.03, "linear", "linear"))]
+            folder = tmp_path / f"scene_{i:03d}"
+            meta = json.load(open(folder / "metadata_out.json"))
+            assert meta["time"] > 0 and list(meta["events"]) == ["e0", "e1", "e2"]
+            for mic, h in irs.items():
+                spat = [orc.render_event(c, h[:, [k], :].astype(np.float64), 8.0 + 3 * k, ref_db=-60, sr=sr)["spatial"]
+                        for k, c in enumerate(clips)]
+                slots = [(e.scene_start, e.scene_end) for e in scene.events.values()]
+                want = orc.mix_scene(spat, slots, dur, sr, keep_padded=False)["scene"]
+                rate, wav = wavfile.read(str(folder / f"audio_out_{mic}.wav"))
+                assert rate == sr and wav.shape == want.T.shape
+                assert rel_rms(wav.T, want) < TOL
+        again = batch.render_dataset(((f"scene_{i:03d}", factory(i)) for i in range(4)), str(tmp_path), subtype="FLOAT")
+        assert again.n_scenes == 2 and built == [0, 1, 2, 3] and sorted(again.skipped) == ["scene_000", "scene_001", "scene_002"]
+    finally:
+        syn.set_renderer(None)
 
 
 def test_hip_graph_replay_matches_eager(gpu):

@@ -62,19 +62,35 @@ def test_scene_generate_matches_reference(golden):
 def test_render_cache_and_host_arrays(golden):
     scene = build_g8_scene(golden, with_ambience=False)
     syn.render_audio_for_all_scene_events(scene)
-    first = scene.events["ev0"]._al_device["mic000"][0]
+    ev0 = scene.events["ev0"]
+    first = ev0.spatial_audio.device_source("mic000")[0]
     syn.render_audio_for_all_scene_events(scene)                 # cached: nothing re-rendered (synthesize.py:541-542)
-    assert scene.events["ev0"]._al_device["mic000"][0] is first
+    assert ev0.spatial_audio.device_source("mic000")[0] is first
     syn.render_audio_for_all_scene_events(scene, ignore_cache=True)
-    assert scene.events["ev0"]._al_device["mic000"][0] is not first
+    assert ev0.spatial_audio.device_source("mic000")[0] is not first
+    assert first.keep == ()                                       # a result does not pin the spectra workspace
     # events rendered elsewhere (plain ndarrays in spatial_audio) are mixed as well
     for ev in scene.events.values():
         host = ev.spatial_audio["mic000"]
         ev.spatial_audio = {"mic000": host}
-        ev._al_device = {}
     syn.generate_scene_audio_from_events(scene)
     want = golden["g8_scene"].astype(np.float64) - orc.db_gain(-65, np.mean(np.abs(golden["g8_ambience"]))) * golden["g8_ambience"]
     assert rel_rms(scene.audio["mic000"], want) < 2e-4
+    # the mixdown must follow what event.spatial_audio[mic] holds NOW (reference synthesize.py:372-378), not a stale
+    # device render: edit one event after rendering, then clear another
+    scene2 = build_g8_scene(golden, with_ambience=False)
+    syn.render_audio_for_all_scene_events(scene2)
+    e1 = scene2.events["ev1"]
+    e1.spatial_audio["mic000"] = np.zeros_like(e1.spatial_audio["mic000"])      # user post-processing: silence it
+    assert e1.spatial_audio.device_source("mic000") is None
+    syn.generate_scene_audio_from_events(scene2)
+    sr, n1 = 8000, golden["g8_spatial1"].shape[1]
+    lo = round(float(golden["g8_specs"][1][2]) * sr)
+    want2 = want.copy()
+    want2[:, lo: lo + n1] -= golden["g8_spatial1"]
+    assert rel_rms(scene2.audio["mic000"], want2) < 2e-4
+    scene2.events["ev0"].clear_audio()
+    assert scene2.events["ev0"].spatial_audio.device_source("mic000") is None
 
 
 def test_render_event_audio_and_errors(golden):
@@ -309,3 +325,41 @@ def test_stft_helpers_match_reference():
     assert rel_rms(tv[:, : chain.shape[1]], chain[:, : tv.shape[1]]) < TOL
     with pytest.raises(Exception, match="fft_size must factor"):
         syn.stft(a, 2 * 11 * 13, 256, 128)
+
+
+def test_fx_chain_stays_on_device_and_scalars_fold():
+    """BASELINE configs[4]'s "gain/polarity augmentations fused" through the PRODUCT classes: events built with
+    ``augmentations=[Gain, Invert]`` render to what the oracle gives for peak_normalise(invert(gain(raw))) with no FX
+    kernel and no clip statistic crossing PCIe (the scalar is evaluated on the device and folded into the spectra);
+    a chain with non-scalar FX runs on ONE device-resident clip and is handed to the renderer in HBM (event.py:529-539,
+    augmentation.py:91-136)."""
+    rng = np.random.default_rng(11)
+    sr, C, L = 8000, 3, 700
+    raws = [rng.standard_normal(n).astype(np.float32) * s for n, s in ((3000, 0.3), (2500, 2.0), (2800, 1.0))]
+    irs = (rng.standard_normal((C, 3, L)) * np.exp(-np.arange(L) / 150.0)).astype(np.float32)
+    chains = [[aug.Gain(sr, gain_db=-4.0), aug.Invert(sr)],                       # pure scalars: folded
+              [aug.Invert(sr), aug.Gain(sr, gain_db=7.5), aug.Invert(sr)],         # folded, net positive
+              [aug.Fade(sr, 0.05, 0.1, "linear", "half_sine"), aug.Gain(sr, gain_db=2.0), aug.Reverse(sr)]]   # device chain
+    scene = core.Scene(1.0, core.StaticIRState({"mic000": irs}), sample_rate=sr, ref_db=-65)
+    for i, (raw, chain) in enumerate(zip(raws, chains)):
+        scene.add_event(core.Event(f"e{i}", raw, sr, snr=10.0 + i, scene_start=0.1 * i, augmentations=chain))
+    assert aug.fold_scalars(chains[0]) == pytest.approx(-(10 ** (-4.0 / 20)), rel=1e-6) and aug.fold_scalars(chains[2]) is None
+    scene.generate()
+    want_clips = [orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(raws[0], -4.0))),
+                  orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(orc.fx_invert(raws[1]), 7.5))),
+                  orc.peak_normalise_clip(orc.fx_reverse(orc.fx_gain(orc.fx_fade(raws[2], sr, 0.05, 0.1, "linear", "half_sine"), 2.0)))]
+    spatials = []
+    for i, ev in enumerate(scene.events.values()):
+        want = orc.render_event(want_clips[i], irs[:, [i], :].astype(np.float64), ev.snr, sr=sr)["spatial"]
+        spatials.append(want)
+        assert rel_rms(ev.spatial_audio["mic000"], want) < TOL
+        assert ev.audio is None                         # nobody asked for the host clip: it never came back
+    assert getattr(scene.events["e0"], "_last_chain", None) is None          # folded: no FX kernel, no device clip
+    chain_clip = scene.events["e2"]._last_chain
+    assert chain_clip.uploads == 1 and chain_clip.downloads == 0            # three FX + normalisation, zero D2H
+    ref = orc.mix_scene(spatials, [(e.scene_start, e.scene_end) for e in scene.events.values()], 1.0, sr, keep_padded=False)["scene"]
+    assert rel_rms(scene.audio["mic000"], ref) < TOL
+    # the host API still gives the reference's answer, through one upload and one download
+    ev = core.Event("h", raws[2], sr, augmentations=chains[2])
+    assert rel_rms(ev.load_audio(), want_clips[2]) < 1e-6
+    assert ev._last_chain.uploads == 1 and ev._last_chain.downloads == 1

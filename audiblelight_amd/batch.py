@@ -50,6 +50,7 @@ class BatchReport:
     files: List[str] = field(default_factory=list)
     skipped: List[str] = field(default_factory=list)     # scenes left alone because their output exists
     latencies: dict = field(default_factory=dict)        # scene name -> seconds from staging to written / delivered
+    host_s: dict = field(default_factory=dict)           # producer-thread seconds by stage: stage / enqueue / wait_writer
 
     @property
     def scene_seconds_per_second(self) -> float:
@@ -83,6 +84,8 @@ class BatchDriver:
         self.down_stream = self.torch.cuda.Stream(device=dev)
         self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
         self._slot_ready = {}   # slot -> H2D event of the scene that last used the slot's pinned clip buffer
+        # default: the runtime's pageable copy (holds this thread); AL_H2D=async: page-lock in place + asynchronous DMA
+        self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
         key = (tag, dtype, int(numel))
@@ -110,13 +113,14 @@ class BatchDriver:
                 src = engine.as_clip_source(clip)
                 if src.host is None:
                     audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]
-            irs_dev, strides = r.upload_irs(job.irs)             # straight from the caller's memory
+            release = [] if self.async_h2d else None
+            irs_dev, strides = r.upload_irs(job.irs, async_release=release)   # straight from the caller's memory
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         self._slot_ready[slot] = ready
         h2d = job.irs.nbytes + pl.audio_floats * 4
         return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=strides, audio=audio_dev, ready=ready,
-                    h2d=h2d, slot=slot, t0=time.perf_counter())
+                    h2d=h2d, slot=slot, t0=time.perf_counter(), release=release or [])
 
     # -- stage 2: kernels on the current (compute) stream
     def _render(self, st):
@@ -127,8 +131,11 @@ class BatchDriver:
         st["irs"].record_stream(cur)
         st["audio"].record_stream(cur)
         batch = r.prepare(st["plan"], st["job"].clips, st["irs"], st["strides"], audio_dev=st["audio"])
+        # every table upload (small blocking copies) BEFORE the first launch: a blocking copy behind the render kernels
+        # on the same stream would hold this thread for the whole render
+        mix = r.prepare_mixdown(st["mix"], batch.result(), st["job"].ambience)
         res = batch.run()
-        scene = r.prepare_mixdown(st["mix"], res, st["job"].ambience).run()
+        scene = mix.run()
         st.update(result=res, scene=scene, batch=batch)
         return st
 
@@ -168,12 +175,13 @@ class BatchDriver:
     def run(self, jobs: Iterable[SceneJob], output_dir: Optional[str] = None,
             on_scene: Optional[Callable[[str, np.ndarray], None]] = None, check_finite: bool = True,
             subtype: Optional[str] = None, skip_existing: bool = False,
-            path_of: Optional[Callable[[SceneJob], str]] = None) -> BatchReport:
+            path_of: Optional[Callable[[SceneJob], str]] = None, copy_for_callback: bool = True) -> BatchReport:
         """Render all jobs.  With ``output_dir`` every scene is written to ``<output_dir>/<name>.wav`` (or
         ``path_of(job)``): (T, C) interleaved frames like ``soundfile.write(audio.T, sr)`` (core.py:1840-1847), subtype
         ``PCM_16`` (soundfile's default for WAV) or ``FLOAT``; ``skip_existing`` leaves scenes whose file exists alone
         (scripts/generate/benchmark.py:54-55).  ``on_scene(name, array)`` receives a (C, T) float32 array of its own
-        (a copy: the page-locked download buffers are reused a few scenes later).  A failure in the writer thread
+        (a copy: the page-locked download buffers are reused ``depth + 3`` scenes later; ``copy_for_callback=False``
+        hands out the view instead, for callbacks that consume it before returning).  A failure in the writer thread
         (non-finite audio, disk error, callback error) stops the run and is re-raised here."""
         subtype = subtype or self.subtype
         if subtype not in SUBTYPES:
@@ -187,6 +195,8 @@ class BatchDriver:
 
         def write_one(st):
             st["landed"].synchronize()
+            for release in st.get("release", ()):   # the scene is out, so its H2D copy is long done: unpin the caller's IRs
+                release()
             if check_finite:
                 st["result"].check_finite()
             c, t = st["mix"].n_capsules, st["mix"].n_samples
@@ -199,7 +209,8 @@ class BatchDriver:
                 rep.files.append(path)
                 rep.d2h_bytes += st["frames"].numel() * st["frames"].element_size()
             if want_scene:
-                on_scene(st["job"].name, st["host"].numpy().reshape(c, t).copy())
+                view = st["host"].numpy().reshape(c, t)
+                on_scene(st["job"].name, view.copy() if copy_for_callback else view)
                 rep.d2h_bytes += c * t * 4
             rep.latencies[st["job"].name] = time.perf_counter() - st["t0"]
 
@@ -237,15 +248,21 @@ class BatchDriver:
             staged = self._stage(nxt, index % n_slots) if nxt is not None else None
             while staged is not None and not failure:
                 cur = staged
+                ta = time.perf_counter()
                 st = self._download(self._render(cur), want_frames, want_scene, subtype)   # enqueue only (asynchronous)
+                tb = time.perf_counter()
                 nxt = next_job(it)
                 index += 1
                 # the upload of scene i+1 (host-blocking, PCIe-bound) runs while the GPU renders scene i
                 staged = self._stage(nxt, index % n_slots) if nxt is not None else None
+                tc = time.perf_counter()
                 rep.n_scenes += 1
                 rep.scene_seconds += cur["job"].duration
                 rep.h2d_bytes += cur["h2d"]
                 sink.put(st)          # blocks while the writer is `depth` + 1 scenes behind: back-pressure
+                td = time.perf_counter()
+                for key, dt in (("enqueue", tb - ta), ("stage", tc - tb), ("wait_writer", td - tc)):
+                    rep.host_s[key] = rep.host_s.get(key, 0.0) + dt
         finally:
             sink.put(None)
             th.join()

@@ -51,6 +51,40 @@ class TorchMemory:
             arr = arr.view(np.uint8)
         return self.torch.from_numpy(arr).to(self.device, non_blocking=False)
 
+    def upload_staged(self, n: int, fill) -> object:
+        """float32[n] assembled by ``fill(host_view)`` in a REUSED page-locked staging buffer, then one asynchronous DMA:
+        for inputs that have to be packed on the host anyway (the clips of a scene).  A fresh pageable buffer would cost
+        a page fault per 4 KiB before the copy even starts."""
+        if not hasattr(self, "_staging"):
+            self._staging = {}
+        key = int(n)
+        if key not in self._staging:
+            if len(self._staging) >= 4:          # a few scene shapes at most; drop the oldest
+                self._staging.pop(next(iter(self._staging)))
+            self._staging[key] = [self.torch.empty(key, dtype=self.torch.float32, pin_memory=True), None]
+        host, last = self._staging[key]
+        if last is not None:
+            last.synchronize()                   # the previous DMA out of this buffer must have finished
+        fill(host.numpy())
+        dev = host.to(self.device, non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        self._staging[key][1] = ev
+        return dev
+
+    def upload_async(self, arr: np.ndarray):
+        """Large caller-owned array -> HBM by DMA without holding the calling thread: the array's pages are page-locked in
+        place (hipHostRegister), the copy is enqueued on the current stream, and the returned ``release()`` must be
+        called once that copy has completed (it unregisters the pages).  Falls back to ``upload`` when registration fails."""
+        arr = np.ascontiguousarray(arr)
+        rt = self.torch.cuda.cudart()
+        if int(rt.cudaHostRegister(arr.ctypes.data, arr.nbytes, 0)) != 0:
+            return self.upload(arr), (lambda: None)
+        src = self.torch.from_numpy(arr.reshape(-1))
+        dev = self.torch.empty(src.numel(), dtype=src.dtype, device=self.device)
+        dev.copy_(src, non_blocking=True)
+        return dev, (lambda p=arr.ctypes.data, keep=arr: rt.cudaHostUnregister(p))
+
     def ptr(self, buf) -> int:
         return buf.data_ptr()
 
@@ -143,8 +177,10 @@ class Renderer:
         return self._twiddles[log2_block]
 
     # -- IR upload: (C, N, L) any float dtype -> float32 device tensor with 4-float aligned rows
-    def upload_irs(self, irs: np.ndarray):
-        """The caller's (C, N, L) tensor goes to HBM AS IT IS (no host-side copy, cast or padding pass: the H2D copy of
+    def upload_irs(self, irs: np.ndarray, async_release: Optional[list] = None):
+        """``async_release``: a list; when given and the memory provider can do it, the H2D copy is an asynchronous DMA
+        from the caller's page-locked-in-place array and a ``release`` callable is appended (call it after the copy).
+        The caller's (C, N, L) tensor goes to HBM AS IT IS (no host-side copy, cast or padding pass: the H2D copy of
         pageable memory runs at PCIe rate, a fresh ``np.zeros`` + copy at a fifth of it, profiles/r02_h2d_probe.txt);
         float64 (what ``WorldState.get_irs()`` returns, worldstate.py:2183-2255) and rows whose length is not a
         multiple of 4 are converted / re-pitched by a device kernel."""
@@ -154,7 +190,11 @@ class Renderer:
             return self.mem.zeros(max(c, 1) * lp), (lp, lp)
         if irs.dtype not in (np.float32, np.float64):
             irs = irs.astype(np.float32)
-        raw = self.mem.upload(np.ascontiguousarray(irs).reshape(-1))
+        if async_release is not None and hasattr(self.mem, "upload_async"):
+            raw, release = self.mem.upload_async(np.ascontiguousarray(irs).reshape(-1))
+            async_release.append(release)
+        else:
+            raw = self.mem.upload(np.ascontiguousarray(irs).reshape(-1))
         if irs.dtype == np.float32 and lp == l:
             return raw, (n * lp, lp)
         dev = self.mem.empty(c * n * lp)
@@ -191,7 +231,10 @@ class Renderer:
         lanes = max(1, min(int(lanes), len(chunks)))
         sources = [as_clip_source(c) for c in clips]
         if audio_dev is None:
-            audio_dev = mem.upload(self.pack_audio(plan, sources))
+            if hasattr(mem, "upload_staged"):
+                audio_dev = mem.upload_staged(plan.audio_floats, lambda view: self.pack_audio(plan, sources, out=view))
+            else:
+                audio_dev = mem.upload(self.pack_audio(plan, sources))
             for off, src in zip(plan.audio_offsets, sources):   # clips that are already in HBM (device FX chain): D2D
                 if src.host is None:
                     audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]

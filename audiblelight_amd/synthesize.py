@@ -385,8 +385,12 @@ def generate_scene_audio_from_events(scene) -> None:
             scene_dev = pm.run()
             first = False
             _attach_padded(events, idxs, mix, mic_alias, channels, duration)
+        # librosa.util.valid_audio (synthesize.py:398) as a device reduction: a host pass over the scene costs more
+        # than rendering it
+        stats = r.mem.download(r.row_stats(scene_dev, 1, channels * duration)).reshape(-1, 4)
+        if stats[0, 2] > 0 or not np.isfinite(stats[0, 0]):
+            raise ValueError("Audio buffer is not finite everywhere")
         host = r.mem.download(scene_dev)[: channels * duration].reshape(channels, duration)
-        valid_audio(host)
         validate_shape(host.shape, (channels, duration))
         scene.audio[mic_alias] = host
 

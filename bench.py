@@ -128,6 +128,37 @@ def load_pmc_traffic(config: str, log2_block: int):
     return table.get(f"{config}/log2_block={log2_block}"), f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {table.get('collected', '')}"
 
 
+def dropin_leg(scene, renderer, n: int):
+    """The reference's own call sequence on this package's objects: a Scene built from host numpy clips + IRs,
+    ``Scene.generate()`` = render_audio_for_all_scene_events + generate_scene_audio_from_events (core.py:1828-1847),
+    ``scene.audio[mic]`` back as a host ndarray.  Synchronous, one scene at a time, PCIe both ways inside the timing."""
+    from audiblelight_amd import augmentation as aug, core, synthesize as syn
+
+    syn.set_renderer(renderer)
+
+    def one():
+        sc = core.Scene(scene.duration, core.StaticIRState({"mic000": scene.irs}), sample_rate=scene.sr, ref_db=-65)
+        for i, (clip, sp) in enumerate(zip(scene.clips, scene.specs)):
+            fx = [aug.Gain(scene.sr, gain_db=scene.gain_db[i]), aug.Invert(scene.sr)] if scene.gain_db is not None else []
+            sc.add_event(core.Event(f"e{i}", clip, scene.sr, snr=sp.snr, scene_start=scene.starts[i], augmentations=fx))
+        audio = sc.generate()["mic000"]
+        assert audio.shape == (scene.n_capsules, round(scene.duration * scene.sr)) and audio.dtype == np.float32
+        return audio
+
+    try:
+        for _ in range(2):
+            one()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            one()
+        dt = (time.perf_counter() - t0) / n
+    finally:
+        syn.set_renderer(None)
+    return {"value": scene.duration / dt, "unit": "scene-seconds/s", "ms_per_scene": dt * 1e3, "scenes": n,
+            "note": "Scene.generate() per scene, synchronous: host float32 clips + IR tensor in (H2D), render, mixdown, "
+                    "scene.audio out as a host ndarray (D2H); NOT the headline value"}
+
+
 def source_hash() -> str:
     """Hash of the kernel sources: ties profiles/pmc_traffic.json to the build it was measured on."""
     import hashlib
@@ -172,8 +203,12 @@ def main():
     ap.add_argument("--cpu-events", type=int, default=16, help="events timed for the CPU baseline (0 = skip)")
     ap.add_argument("--cpu-workers", type=int, default=0, metavar="N",
                     help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64)")
-    ap.add_argument("--end-to-end", type=int, default=0, metavar="N",
-                    help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate)")
+    ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
+                    help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; "
+                         "default 8 on one GPU, 0 otherwise)")
+    ap.add_argument("--dropin", type=int, default=None, metavar="N",
+                    help="also time N calls of Scene.generate() (the drop-in API: host numpy clips + IRs in, scene.audio "
+                         "out, synchronous; default 5 on one GPU for static configs, 0 otherwise)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches; the per-stage "
                          "times then come from a separate eager pass")
@@ -192,6 +227,10 @@ def main():
                  f"(python bench.py --gpus N spawns them itself)")
     if args.gather is None:
         args.gather = world > 1
+    if args.end_to_end is None:
+        args.end_to_end = 8 if world == 1 else 0
+    if args.dropin is None:
+        args.dropin = 5 if world == 1 else 0
     emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements
 
     import torch
@@ -333,13 +372,16 @@ def main():
         jobs = [batch_mod.SceneJob(specs=scene.specs, clips=scene.clips, irs=scene.irs, starts=scene.starts, ends=scene.ends,
                                    duration=scene.duration, sample_rate=scene.sr, name=f"s{i}") for i in range(args.end_to_end)]
         driver = batch_mod.BatchDriver(r)
-        driver.run(jobs[:3], on_scene=lambda name, arr: None)   # warm-up: page-locks the staging buffers once
-        rep = driver.run(jobs, on_scene=lambda name, arr: None)
+        consume = lambda name, arr: None   # noqa: E731  (scene.audio delivered as a (C, T) float32 host array)
+        driver.run((jobs * 2)[:6], on_scene=consume, copy_for_callback=False)   # warm-up: page-locks every staging slot once
+        rep = driver.run(jobs, on_scene=consume, copy_for_callback=False)
         out["end_to_end"] = {"value": rep.scene_seconds_per_second, "unit": "scene-seconds/s", "scenes": rep.n_scenes,
                              "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
                              "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
-                             "note": "host float32 clips+IRs -> pinned staging -> H2D -> render -> D2H of scene.audio, pipelined "
-                                     "over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+                             "note": "host float32 clips+IRs -> H2D -> render -> D2H of scene.audio into page-locked host memory, "
+                                     "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+    if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
+        out["end_to_end_dropin"] = dropin_leg(scene, r, args.dropin)
     if args.gather and world > 1:
         from audiblelight_amd import distributed
 

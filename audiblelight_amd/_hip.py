@@ -87,6 +87,8 @@ SYMBOLS = {
     "al_row_stats_partials": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_fx_apply": (ct.c_int, [ct.c_int, _P, _P, ct.c_int64, _P, _P, _S]),
     "al_fx_frame_shuffle": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _P, ct.c_int32, _S]),
+    "al_pack_ragged_irs": (ct.c_int, [_P, ct.c_int32, _P, _P, ct.c_int64, ct.c_int32, _P, _S]),
+    "al_resample_poly": (ct.c_int, [_P, ct.c_int32, ct.c_int64, _P, ct.c_int32, ct.c_int32, ct.c_int32, _P, ct.c_int64, ct.c_int64, _S]),
     "al_encode_frames": (ct.c_int, [_P, ct.c_int32, ct.c_int64, ct.c_int32, _P, _S]),
     "al_wrap_copy": (ct.c_int, [_P, ct.c_int64, _P, ct.c_int64, _S]),
     "al_pack_irs_f64": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),

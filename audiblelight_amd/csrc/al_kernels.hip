@@ -602,6 +602,38 @@ __global__ __launch_bounds__(256) void k_pack_irs(const T *src, float *dst, int 
   for (int t = threadIdx.x; t < pitch; t += 256) out[t] = t < len ? (float)row[t] : 0.f;
 }
 
+// Ragged IRs (one 1-D array per (capsule, source), worldstate.py:2196-2253) -> zero-padded float32 rows of `pitch`.
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_ragged(const T *__restrict__ src, const int64_t *__restrict__ offsets,
+                                                     const int32_t *__restrict__ lens, float *__restrict__ dst, int pitch) {
+  const int64_t row = blockIdx.x;
+  const T *in = src + offsets[row];
+  const int n = lens[row];
+  float *out = dst + row * pitch;
+  for (int t = threadIdx.x; t < pitch; t += 256) out[t] = t < n ? (float)in[t] : 0.f;
+}
+
+// Polyphase FIR resampling by up/down (scipy.signal.resample_poly semantics: zero-stuff by `up`, filter with h of
+// 2*half+1 taps already scaled by `up`, keep every `down`-th sample): out[m] = sum_j x[j] * h[m*down - j*up + half].
+__global__ __launch_bounds__(256) void k_resample_poly(const float *__restrict__ x, int64_t n_in, const float *__restrict__ h,
+                                                       int half, int up, int down, float *__restrict__ out, int64_t n_out,
+                                                       int64_t out_pitch) {
+  const float *row = x + (int64_t)blockIdx.y * n_in;
+  float *dst = out + (int64_t)blockIdx.y * out_pitch;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < out_pitch; m += (int64_t)gridDim.x * 256) {
+    float acc = 0.f;
+    if (m < n_out) {
+      const int64_t c = m * down;  // position on the up-sampled grid
+      // taps with 0 <= c - j*up + half <= 2*half  <=>  (c - half)/up <= j <= (c + half)/up
+      int64_t j_lo = (c - half + up - 1) / up, j_hi = (c + half) / up;
+      if (c - half < 0) j_lo = 0;
+      if (j_hi > n_in - 1) j_hi = n_in - 1;
+      for (int64_t j = j_lo; j <= j_hi; ++j) acc = fmaf(row[j], h[c - j * up + half], acc);
+    }
+    dst[m] = acc;
+  }
+}
+
 // (C, T) float32 scene -> (T, C) interleaved frames, the layout soundfile.write(audio.T) puts on disk (core.py:1840-1847).
 // One workgroup per tile of 32 capsules x 64 samples through LDS: reads run along t, writes along c.
 template <bool PCM16>
@@ -1107,6 +1139,30 @@ int al_pack_irs_f32(const float *src, float *dst, int64_t rows, int32_t len, int
     return fail(AL_E_BADARG, "bad pack_irs arguments");
   hipLaunchKernelGGL(al::k_pack_irs<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, src, dst, len, dst_pitch);
   return check_launch("k_pack_irs<float>");
+}
+
+int al_pack_ragged_irs(const void *src, int32_t src_is_f64, const int64_t *offsets, const int32_t *lens, int64_t rows,
+                       int32_t dst_pitch, float *dst, al_stream_t stream) {
+  if (!src || !offsets || !lens || !dst || rows <= 0 || rows > 0x7fffffff || dst_pitch <= 0 || (dst_pitch & 3))
+    return fail(AL_E_BADARG, "bad pack_ragged_irs arguments");
+  if (src_is_f64)
+    hipLaunchKernelGGL(al::k_pack_ragged<double>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const double *>(src), offsets, lens, dst, dst_pitch);
+  else
+    hipLaunchKernelGGL(al::k_pack_ragged<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                       static_cast<const float *>(src), offsets, lens, dst, dst_pitch);
+  return check_launch("k_pack_ragged");
+}
+
+int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *taps, int32_t half_len, int32_t up, int32_t down,
+                     float *out, int64_t n_out, int64_t out_pitch, al_stream_t stream) {
+  if (!x || !taps || !out || rows <= 0 || rows > 65535 || n_in <= 0 || half_len < 0 || up <= 0 || down <= 0 || n_out <= 0 ||
+      out_pitch < n_out)
+    return fail(AL_E_BADARG, "bad resample_poly arguments");
+  const int64_t blocks = (out_pitch + 255) / 256;
+  hipLaunchKernelGGL(al::k_resample_poly, dim3((unsigned)(blocks < 4096 ? blocks : 4096), rows), dim3(256), 0, (hipStream_t)stream,
+                     x, n_in, taps, half_len, up, down, out, n_out, out_pitch);
+  return check_launch("k_resample_poly");
 }
 
 int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream) {

@@ -220,7 +220,7 @@ class Renderer:
         ``lanes``: number of workspaces / HIP streams the chunks alternate over (chunk i runs on lane i % lanes),
         so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another."""
         mem = self.mem
-        if isinstance(irs, np.ndarray):
+        if ir_strides is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
             irs, ir_strides = self.upload_irs(irs)
         B = plan.block
         chunks = plan.chunks(chunk_events)

@@ -393,6 +393,34 @@ def generate_scene_audio_from_events(scene) -> None:
         host = r.mem.download(scene_dev)[: channels * duration].reshape(channels, duration)
         validate_shape(host.shape, (channels, duration))
         scene.audio[mic_alias] = host
+        # the mixed scene stays in HBM too: Scene.generate encodes the WAV frames from it on the device (al_encode_frames)
+        try:
+            if not hasattr(scene, "_al_device_audio"):
+                scene._al_device_audio = {}
+            scene._al_device_audio[mic_alias] = (scene_dev, channels, duration, host)
+        except AttributeError:
+            pass
+
+
+def encode_scene_frames(scene, mic_alias: str, subtype: str = "PCM_16") -> np.ndarray:
+    """(T, C) frames of ``scene.audio[mic]`` as ``soundfile.write(audio.T, sr)`` stores them (core.py:1840-1847):
+    int16 for ``PCM_16`` (soundfile's default subtype for WAV; lrint(x * 32767), saturated) or float32 for ``FLOAT``.
+    Interleaving and quantisation run on the device, from the resident mix when ``scene.audio[mic]`` is still the
+    array this package produced, else from an upload of it."""
+    from . import _hip
+
+    fmt, dtype = {"PCM_16": (_hip.FRAMES_PCM16, np.int16), "FLOAT": (_hip.FRAMES_F32, np.float32)}[subtype]
+    r = get_renderer()
+    host = scene.audio[mic_alias]
+    held = getattr(scene, "_al_device_audio", {}).get(mic_alias)
+    if held is not None and held[3] is host:
+        dev, c, t = held[0], held[1], held[2]
+    else:
+        c, t = host.shape
+        dev = r.mem.upload(np.ascontiguousarray(host, dtype=np.float32).reshape(-1))
+    out = r.mem.empty(c * t, dtype)
+    r.lib.call("al_encode_frames", r.mem.ptr(dev), c, t, fmt, r.mem.ptr(out), r.mem.stream())
+    return r.mem.download(out)[: c * t].reshape(t, c)
 
 
 def _ambience_on_device(r: engine.Renderer, ambience, shape):

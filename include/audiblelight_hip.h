@@ -254,6 +254,19 @@ int al_pack_irs_f64(const double *src, float *dst, int64_t rows, int32_t len, in
  * worldstate.py:2236-2253): the caller's array goes to HBM as it is and is laid out on the device. */
 int al_pack_irs_f32(const float *src, float *dst, int64_t rows, int32_t len, int32_t dst_pitch, al_stream_t stream);
 
+/* Ragged ingest: the ray tracer hands out one 1-D IR per (capsule, source) of varying length, which the reference
+ * zero-pads into (C, N, maxlen) with a four-deep Python loop run twice (worldstate.py:2196-2253).  Here the IRs are
+ * concatenated once (`src`, float32 or float64) and laid out on the device: row r = src[offsets[r] : offsets[r]+lens[r]]
+ * followed by zeros up to dst_pitch (multiple of 4).  offsets / lens are device arrays. */
+int al_pack_ragged_irs(const void *src, int32_t src_is_f64, const int64_t *offsets, const int32_t *lens, int64_t rows,
+                       int32_t dst_pitch, float *dst, al_stream_t stream);
+/* Rational-ratio resampling of `rows` series (SOFA IRs at another sample rate, worldstate.py:2995-3006): polyphase FIR,
+ * out[m] = sum_j x[j] * taps[m*down - j*up + half_len], m < n_out (zeros up to out_pitch): scipy.signal.resample_poly
+ * semantics with the caller's `taps` (2*half_len+1 floats, already scaled by `up`).  The reference calls
+ * librosa.resample (soxr), an un-vendored dependency: parity with IT is unpinned; this is pinned to resample_poly. */
+int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *taps, int32_t half_len, int32_t up, int32_t down,
+                     float *out, int64_t n_out, int64_t out_pitch, al_stream_t stream);
+
 /* Output encoding for the WAV writer: (C, T) float32 scene -> (T, C) interleaved frames as
  * soundfile.write(mic_audio.T, sr) stores them (core.py:1840-1847).  AL_FRAMES_PCM16 is soundfile's default subtype for
  * WAV: int16 = lrint(x * 32767) (libsndfile's float->short normalisation), saturated; AL_FRAMES_F32 keeps float32.

@@ -34,6 +34,8 @@ test_scene_json_round_trip = scenarios.test_scene_json_round_trip
 test_scene_generate_argument_list = scenarios.test_scene_generate_argument_list
 test_stft_helpers_match_reference = scenarios.test_stft_helpers_match_reference
 test_fx_chain_stays_on_device_and_scalars_fold = scenarios.test_fx_chain_stays_on_device_and_scalars_fold
+test_reference_format_scene_json_renders_like_the_reference = scenarios.test_reference_format_scene_json_renders_like_the_reference
+test_ir_ingest_ragged_packing_and_resampling = scenarios.test_ir_ingest_ragged_packing_and_resampling
 
 
 def test_large_noise_lengths_statistics():

@@ -273,8 +273,47 @@ def test_scene_json_round_trip(golden, tmp_path):
     path = str(tmp_path / "scene.json")
     scene.to_json(path)
     again = core.Scene.from_json(path, clips={a: e._raw for a, e in scene.events.items()}, irs=dict(scene.state.irs))
-    assert again.to_dict() == scene.to_dict()
+    strip = lambda d: {k: v for k, v in d.items() if k != "creation_time"}   # noqa: E731
+    assert strip(again.to_dict()) == strip(scene.to_dict())
     np.testing.assert_array_equal(again.generate()["mic000"], first)
+
+
+def test_reference_format_scene_json_renders_like_the_reference(tmp_path):
+    """metadata written by the REFERENCE's own Scene/Event/Ambience/MicArray ``to_dict`` code
+    (tests/golden/reference_scene.json, made by tests/golden/make_scene_json.py; core.py:2106-2130, event.py:568-620,
+    ambience.py:219-233) + the arrays it does not carry -> ``Scene.from_json`` -> ``generate()`` equals what the
+    reference rendered for that scene: static, FX-chained, moving and dry-path events, ambience, two microphones."""
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "reference_scene_arrays.npz"))
+    meta = json.load(open(os.path.join(here, "reference_scene.json")))
+    clips = {a: z[f"clip_{a}"] for a in meta["events"]}
+    irs = {m: z[f"irs_{m}"] for m in meta["state"]["microphones"]}
+    scene = core.Scene.from_json(os.path.join(here, "reference_scene.json"), clips, irs)
+    assert [len(e) for e in scene.events.values()] == [1, 1, 4, 1] and scene.events["event002"].is_moving
+    assert [type(a).__name__ for a in scene.events["event001"].augmentations] == ["Gain", "Invert"]
+    out = scene.generate(output_dir=str(tmp_path), audio_subtype="FLOAT")
+    for mic in irs:
+        assert rel_rms(out[mic], z[f"scene_{mic}"]) < TOL
+        for alias, ev in scene.events.items():
+            assert rel_rms(ev.spatial_audio[mic], z[f"spatial_{mic}_{alias}"]) < TOL
+    assert rel_rms(scene.events["event003"]._spatial_audio_dry["mic000"], z["dry_mic000_event003"]) < TOL
+    # what we write back has the reference's layout: same keys at every level the reference's from_dict reads
+    ours = json.load(open(tmp_path / "metadata_out.json"))
+    assert set(ours) == set(meta)
+    for alias in meta["events"]:
+        assert set(ours["events"][alias]) == set(meta["events"][alias])
+        for k in ("scene_start", "scene_end", "duration", "snr", "num_emitters", "augmentations", "emitters", "class_label",
+                  "filepath", "event_start", "is_moving", "ref_ir_channel", "direct_path_time_ms"):
+            assert ours["events"][alias][k] == meta["events"][alias][k], (alias, k)
+    assert ours["ambience"] == meta["ambience"]
+    assert ours["state"]["microphones"] == meta["state"]["microphones"] and ours["state"]["emitters"] == meta["state"]["emitters"]
+    with pytest.raises(KeyError, match="No clip given"):
+        core.Scene.from_dict(meta, {}, irs)
+    with pytest.raises(ValueError, match="emitter columns"):
+        core.Scene.from_dict(meta, clips, {m: v[:, :3] for m, v in irs.items()})
 
 
 def test_scene_generate_argument_list(golden, tmp_path):
@@ -285,7 +324,11 @@ def test_scene_generate_argument_list(golden, tmp_path):
     scene = build_g8_scene(golden, with_ambience=False)
     out = scene.generate(output_dir=str(tmp_path), audio_fname="mix.wav", metadata_fname="meta")
     sr, data = wavfile.read(str(tmp_path / "mix_mic000.wav"))
-    assert sr == scene.sample_rate and data.dtype == np.float32
+    assert sr == scene.sample_rate and data.dtype == np.int16       # soundfile's default subtype (core.py:1840-1847)
+    np.testing.assert_array_equal(data, np.clip(np.rint(out["mic000"].T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16))
+    scene.generate(output_dir=str(tmp_path), audio_fname="mixf", audio_subtype="FLOAT")
+    sr, data = wavfile.read(str(tmp_path / "mixf_mic000.wav"))
+    assert data.dtype == np.float32
     np.testing.assert_array_equal(data.T, out["mic000"])
     assert (tmp_path / "meta.json").exists()
     with pytest.raises(NotImplementedError):
@@ -363,3 +406,48 @@ def test_fx_chain_stays_on_device_and_scalars_fold():
     ev = core.Event("h", raws[2], sr, augmentations=chains[2])
     assert rel_rms(ev.load_audio(), want_clips[2]) < 1e-6
     assert ev._last_chain.uploads == 1 and ev._last_chain.downloads == 1
+
+
+def test_ir_ingest_ragged_packing_and_resampling(emu_renderer):
+    """(i) ragged per-(capsule, source) IRs -> the zero-padded float32 HBM layout, equal to the
+    reference's zero_arr fill (worldstate.py:2213-2253), and rendered straight from that buffer; (ii) IRs at another
+    sample rate resampled on the device, pinned to scipy.signal.resample_poly (the reference's librosa/soxr resampler
+    is an absent third-party algorithm: unpinned by definition)."""
+    from scipy.signal import resample_poly
+
+    from audiblelight_amd import ingest, plan as planning
+
+    r = emu_renderer
+    rng = np.random.default_rng(5)
+    C, N = 3, 2
+    lens = rng.integers(0, 700, size=(C, N))
+    lens[1, 1] = 0                                         # a silent path
+    nest = [[(rng.standard_normal(lens[c, n]) * np.exp(-np.arange(lens[c, n]) / 120.0)).astype(np.float64 if (c + n) % 2 else np.float32)
+             for n in range(N)] for c in range(C)]
+    dev, strides, maxlen = ingest.pack_ragged_irs(r, nest)
+    want = np.zeros((C, N, maxlen))                        # the reference's zero_arr, filled the reference's way
+    for c in range(C):
+        for n in range(N):
+            want[c, n, : lens[c, n]] = nest[c][n]
+    pitch = strides[1]
+    got = r.mem.download(dev)[: C * N * pitch].reshape(C, N, pitch)
+    np.testing.assert_array_equal(got[:, :, :maxlen], want.astype(np.float32))
+    assert not got[:, :, maxlen:].any() and maxlen == lens.max() and strides == (N * pitch, pitch)
+    clips = [rng.standard_normal(1500).astype(np.float32) for _ in range(N)]
+    specs = [planning.EventSpec(n_samples=1500, n_emitters=1, snr=10.0, emitter0=n) for n in range(N)]
+    pl = planning.plan_batch(specs, C, maxlen, 8000, log2_block=10)
+    res = r.prepare(pl, clips, dev, strides).run()
+    for n in range(N):
+        ref = orc.render_event(clips[n], want[:, [n], :], 10.0, sr=8000)["spatial"]
+        assert rel_rms(res.spatial_audio(n), ref) < TOL
+    # resampling 44.1 kHz -> 48 kHz (160/147) and 48 -> 16 kHz (1/3)
+    h = (rng.standard_normal((2, 3, 900)) * np.exp(-np.arange(900) / 150.0)).astype(np.float32)
+    for a, b in ((44100, 48000), (48000, 16000)):
+        got = ingest.resample_irs(r, h, a, b)
+        up, down = (160, 147) if a == 44100 else (1, 3)
+        ref = resample_poly(h.astype(np.float64), up, down, axis=-1)
+        n_out = int(round(900 * b / a))
+        assert got.shape == (2, 3, n_out) and got.dtype == np.float32
+        m = min(n_out, ref.shape[-1])
+        assert rel_rms(got[..., :m], ref[..., :m]) < 1e-5
+    assert ingest.resample_irs(r, h, 48000, 48000) is not None

@@ -408,7 +408,7 @@ def test_fx_chain_stays_on_device_and_scalars_fold():
     assert ev._last_chain.uploads == 1 and ev._last_chain.downloads == 1
 
 
-def test_ir_ingest_ragged_packing_and_resampling(emu_renderer):
+def test_ir_ingest_ragged_packing_and_resampling():
     """(i) ragged per-(capsule, source) IRs -> the zero-padded float32 HBM layout, equal to the
     reference's zero_arr fill (worldstate.py:2213-2253), and rendered straight from that buffer; (ii) IRs at another
     sample rate resampled on the device, pinned to scipy.signal.resample_poly (the reference's librosa/soxr resampler
@@ -417,7 +417,7 @@ def test_ir_ingest_ragged_packing_and_resampling(emu_renderer):
 
     from audiblelight_amd import ingest, plan as planning
 
-    r = emu_renderer
+    r = syn.get_renderer()   # the module fixture's renderer (host emulation here, the gfx950 build in test_gpu_api.py)
     rng = np.random.default_rng(5)
     C, N = 3, 2
     lens = rng.integers(0, 700, size=(C, N))

@@ -34,8 +34,14 @@ __global__ void k_twiddle_init(float2 *tw, int m) {
 
 // ------------------------------------------------------------------ 2. emitter gains (normalize_irs)
 // one wave per emitter: g = 1 / mean_c( sqrt(sum_t h^2) + tiny(float64) )   (synthesize.py:425-428)
-__global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
+// mode 0: g (single GPU); 1: emitter_gain[n] := sum over THIS rank's capsules of the norms (to be all-reduced);
+// 2: emitter_gain[n] := total_capsules / emitter_gain[n] (the reduced sum), for capsule-sharded scenes
+__global__ __launch_bounds__(64) void k_emitter_gains(al_batch b, int mode, int total_capsules) {
   const int n = b.emitter0 + blockIdx.x, lane = threadIdx.x;
+  if (mode == 2) {
+    if (lane == 0) b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)total_capsules / (double)b.emitter_gain[n]);
+    return;
+  }
   double acc = 0.0;
   for (int c = lane; c < b.n_capsules; c += 64) {
     const float *e = b.ir_energy + ((int64_t)n * b.n_capsules + c) * b.n_partitions;
@@ -45,7 +51,10 @@ __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b) {
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)b.n_capsules / acc);
+  if (lane == 0) {
+    if (mode == 1) b.emitter_gain[n] = (float)acc;
+    else b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)b.n_capsules / acc);
+  }
 }
 
 // ------------------------------------------------------------------ 4. frequency-domain accumulate
@@ -734,8 +743,23 @@ int al_ir_spectra(const al_batch *b, al_stream_t stream) {
 int al_emitter_gains(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_emitters <= 0) return AL_OK;
-  hipLaunchKernelGGL(al::k_emitter_gains, dim3(b->n_emitters), dim3(64), 0, (hipStream_t)stream, *b);
+  hipLaunchKernelGGL(al::k_emitter_gains, dim3(b->n_emitters), dim3(64), 0, (hipStream_t)stream, *b, 0, 0);
   return check_launch("k_emitter_gains");
+}
+
+int al_emitter_norm_sums(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (b->n_emitters <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_emitter_gains, dim3(b->n_emitters), dim3(64), 0, (hipStream_t)stream, *b, 1, 0);
+  return check_launch("k_emitter_gains(sums)");
+}
+
+int al_emitter_gains_from_sums(const al_batch *b, int32_t total_capsules, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (total_capsules < b->n_capsules) return fail(AL_E_BADARG, "total_capsules < n_capsules");
+  if (b->n_emitters <= 0) return AL_OK;
+  hipLaunchKernelGGL(al::k_emitter_gains, dim3(b->n_emitters), dim3(64), 0, (hipStream_t)stream, *b, 2, total_capsules);
+  return check_launch("k_emitter_gains(from sums)");
 }
 
 int al_signal_spectra(const al_batch *b, al_stream_t stream) {
@@ -1041,7 +1065,7 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
     z = x;
   }
   hipLaunchKernelGGL(al::k_noise_unpack, g_len, dim3(256), 0, st, z, n, inv_sigma / (float)p.len, out);
-  return check_launch("al_noise_irfft");
+  return check_launch("al_noise_irfft");  // hipGetLastError keeps the first failure of the sequence until it is read
 }
 
 // ---- STFT-domain intermediates of the moving path (A7), reference signatures kept in audiblelight_amd/synthesize.py

@@ -145,43 +145,26 @@ def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_
     batch = renderer.prepare(pl, clips, irs_local)
     lib, stream = renderer.lib, renderer.mem.stream()
     desc = batch.descs[0]
+    sharded = dist.is_initialized() and dist.get_world_size() > 1
+
+    def as_tensor(buf):   # device tensors as they are; host-emulated memory (CPU tests) through a torch view
+        return torch.from_numpy(buf) if isinstance(buf, np.ndarray) else buf
+
+    # Both exchanges are stream-ordered collectives on device arrays: nothing is copied to the host and nothing waits.
+    # 1. emitter gains are a mean over ALL capsules (normalize_irs, synthesize.py:404-428): all-reduce the norm sums
     lib.call("al_ir_spectra", ct.byref(desc), stream)
-    # emitter gains are a mean over ALL capsules as well (normalize_irs, synthesize.py:404-428): reduce the energies
-    gains = _allreduce_emitter_gains(renderer, batch, total_capsules)
-    batch.bufs["emitter_gain"][: len(gains)] = gains
+    lib.call("al_emitter_norm_sums", ct.byref(desc), stream)
+    if sharded:
+        dist.all_reduce(as_tensor(batch.bufs["emitter_gain"]), op=dist.ReduceOp.SUM)
+    lib.call("al_emitter_gains_from_sums", ct.byref(desc), int(total_capsules), stream)
     for name in ("al_signal_spectra", "al_spectral_mac", "al_block_synthesis", "al_event_stats"):
         lib.call(name, ct.byref(desc), stream)
-    renderer.mem.synchronize()
-    stats = batch.bufs["event_stats"]
-    if isinstance(stats, np.ndarray):  # host-emulated memory (tests): go through torch CPU tensors
-        t = torch.from_numpy(stats).view(-1, 4)
-    else:
-        t = stats.view(-1, 4)
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        sums = t[:, [0, 2]].contiguous()
-        peak = t[:, 1].contiguous()
+    # 2. per-event level statistics {sum|x|, max|x|, non-finite count} over all capsules (synthesize.py:594-599)
+    if sharded:
+        t = as_tensor(batch.bufs["event_stats"]).view(-1, 4)
+        sums, peak = t[:, [0, 2]].contiguous(), t[:, 1].contiguous()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         dist.all_reduce(peak, op=dist.ReduceOp.MAX)
         t[:, 0], t[:, 2], t[:, 1] = sums[:, 0], sums[:, 1], peak
     lib.call("al_event_levels_from_stats", ct.byref(desc), int(total_capsules), stream)
     return batch.result()
-
-
-def _allreduce_emitter_gains(renderer, batch, total_capsules: int):
-    """g[n] = total_capsules / sum_c ||h_{n,c}|| with the norm sum all-reduced over ranks."""
-    import torch
-    import torch.distributed as dist
-
-    pl = batch.plan
-    renderer.mem.synchronize()
-    energy = renderer.mem.download(batch.bufs["ir_energy"])[: pl.hspec_blocks].astype(np.float64)
-    norms = np.sqrt(energy.reshape(pl.n_emitters, pl.n_capsules, pl.n_partitions).sum(axis=2)) + np.finfo(np.float64).tiny
-    total = torch.from_numpy(norms.sum(axis=1))
-    if dist.is_initialized() and dist.get_world_size() > 1:
-        if dist.get_backend() == "nccl":
-            total = total.cuda()
-        dist.all_reduce(total, op=dist.ReduceOp.SUM)
-        total = total.cpu()
-    g = (total_capsules / total.numpy()).astype(np.float32)
-    mem = renderer.mem
-    return mem.upload(g) if not isinstance(batch.bufs["emitter_gain"], np.ndarray) else g

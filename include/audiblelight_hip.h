@@ -168,6 +168,11 @@ int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite l
  * its own capsules into event_stats[e] = {sum|x|, max|x|, non-finite count, -}, the ranks all-reduce those E triples
  * (SUM, MAX, SUM), then every rank evaluates the level law with the TOTAL capsule count. */
 int al_event_stats(const al_batch *b, al_stream_t stream);
+/* The same split for normalize_irs (synthesize.py:404-428), whose mean runs over ALL capsules of the microphone:
+ * al_emitter_norm_sums leaves sum_c ||h_{n,c}|| over this rank's capsules in emitter_gain[n]; the ranks all-reduce (SUM)
+ * that device array; al_emitter_gains_from_sums turns it into total_capsules / sum in place.  No host round trip. */
+int al_emitter_norm_sums(const al_batch *b, al_stream_t stream);
+int al_emitter_gains_from_sums(const al_batch *b, int32_t total_capsules, al_stream_t stream);
 int al_event_levels_from_stats(const al_batch *b, int32_t total_capsules, al_stream_t stream);
 int al_render_batch(const al_batch *b, al_stream_t stream);
 

@@ -29,6 +29,53 @@ __device__ __forceinline__ int opaque_lane(int x) {
   return x;
 }
 
+// ------------------------------------------------------------------ streamed (touch-once) global accesses
+// AL_NT is a bit mask of the sites that use non-temporal loads / stores (experiment switch, see profiles/r02_nt.txt):
+//   1 Y store (accumulate)   2 Y load (synthesis)   4 H / X store (spectra kernels)   8 IR load
+//   16 event audio store (synthesis)   64 scene store (mixdown)
+// Default 81 = Y, event-audio and scene stores: written once, read by a LATER kernel after 1.5-3 GB of other traffic,
+// so keeping them out of the caches is free; measured -3 % on the accumulate and the mixdown.  Non-temporal H / X stores
+// and Y loads cost time (the spectra kernel's own partner workgroups and the synthesis re-use those lines).
+#ifndef AL_NT
+#define AL_NT 81
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float al_v2f __attribute__((ext_vector_type(2)));
+typedef float al_v4f __attribute__((ext_vector_type(4)));
+#endif
+template <int SITE>
+__device__ __forceinline__ void stream_store(float2 *p, const float2 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((AL_NT & SITE) != 0) {
+    al_v2f t = {v.x, v.y};
+    __builtin_nontemporal_store(t, reinterpret_cast<al_v2f *>(p));
+    return;
+  }
+#endif
+  *p = v;
+}
+template <int SITE>
+__device__ __forceinline__ void stream_store(float4 *p, const float4 &v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((AL_NT & SITE) != 0) {
+    al_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<al_v4f *>(p));
+    return;
+  }
+#endif
+  *p = v;
+}
+template <int SITE>
+__device__ __forceinline__ float2 stream_load(const float2 *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((AL_NT & SITE) != 0) {
+    const al_v2f t = __builtin_nontemporal_load(reinterpret_cast<const al_v2f *>(p));
+    return make_float2(t.x, t.y);
+  }
+#endif
+  return *p;
+}
+
 // ------------------------------------------------------------------ block-wide reductions
 // sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
 __device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,

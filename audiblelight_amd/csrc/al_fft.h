@@ -26,6 +26,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "al_common.h"
+
 namespace al {
 
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
@@ -433,8 +435,8 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], 
       const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
       const float2 o = make_float2(d.y, -d.x);
       const float2 wo = cmul(wm, o);
-      out[k] = cadd(e, wo);
-      out[M - k] = cconj(csub(e, wo));
+      stream_store<4>(out + k, cadd(e, wo));
+      stream_store<4>(out + (M - k), cconj(csub(e, wo)));
     }
   }
 }
@@ -447,8 +449,8 @@ __device__ __forceinline__ void real_pack_issue(const float2 *__restrict__ in, f
 #pragma unroll
   for (int m = 0; m < G::H; ++m) {
     const int k = tid + G::T * m;
-    yk[m] = in[k];
-    ym[m] = in[k == 0 ? G::M / 2 : G::M - k];
+    yk[m] = stream_load<2>(in + k);
+    ym[m] = stream_load<2>(in + (k == 0 ? G::M / 2 : G::M - k));
   }
 }
 

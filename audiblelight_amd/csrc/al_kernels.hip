@@ -69,7 +69,7 @@ template <> struct BinVec<1> {
   float2 a;
   __device__ __forceinline__ static BinVec zero() { return BinVec{make_float2(0.f, 0.f)}; }
   __device__ __forceinline__ static BinVec load(const float2 *p) { return BinVec{*p}; }
-  __device__ __forceinline__ void store(float2 *p) const { *p = a; }
+  __device__ __forceinline__ void store(float2 *p) const { stream_store<1>(p, a); }
   __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; }
   // BIN0: this wave may hold bin 0 (packed DC/Nyquist: two real products); every other wave takes the plain path
   template <bool BIN0>
@@ -84,7 +84,7 @@ template <> struct BinVec<2> {
     const float4 v = *reinterpret_cast<const float4 *>(p);
     return BinVec{make_float2(v.x, v.y), make_float2(v.z, v.w)};
   }
-  __device__ __forceinline__ void store(float2 *p) const { *reinterpret_cast<float4 *>(p) = make_float4(a.x, a.y, c.x, c.y); }
+  __device__ __forceinline__ void store(float2 *p) const { stream_store<1>(reinterpret_cast<float4 *>(p), make_float4(a.x, a.y, c.x, c.y)); }
   __device__ __forceinline__ void scale(float g) { a.x *= g; a.y *= g; c.x *= g; c.y *= g; }
   template <bool BIN0>
   __device__ __forceinline__ void fma(const BinVec &x, const BinVec &h, bool packed) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_mixdown(al_mix m) {
   for (int r = 0; r < RUNS; ++r) {
     const int t = t_begin + 4 * (threadIdx.x + 256 * r);
     if (whole) {
-      *reinterpret_cast<float4 *>(row + t) = acc[r];
+      stream_store<64>(reinterpret_cast<float4 *>(row + t), acc[r]);
     } else {
       if (t < m.n_samples) row[t] = acc[r].x;
       if (t + 1 < m.n_samples) row[t + 1] = acc[r].y;

@@ -21,7 +21,7 @@ template <class G>
 __device__ __forceinline__ void load_partition(const float *__restrict__ src, int remaining, int tid, float2 (&x)[G::H]) {
   if (remaining >= G::M) {  // workgroup-uniform
 #pragma unroll
-    for (int m = 0; m < G::H; ++m) x[m] = *reinterpret_cast<const float2 *>(src + 2 * (tid + G::T * m));
+    for (int m = 0; m < G::H; ++m) x[m] = stream_load<8>(reinterpret_cast<const float2 *>(src + 2 * (tid + G::T * m)));
   } else {
     const int last = remaining - 1;
 #pragma unroll
@@ -191,7 +191,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
 #pragma unroll
         for (int m = 0; m < H; ++m) {
           const float2 z = v[H + m];
-          *reinterpret_cast<float2 *>(o + 2 * T * m) = z;
+          stream_store<16>(reinterpret_cast<float2 *>(o + 2 * T * m), z);
           asum += fabsf(z.x) + fabsf(z.y);
           amax = fmaxf(amax, fmaxf(fabsf(z.x), fabsf(z.y)));
         }

@@ -17,6 +17,7 @@ DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
+FLAG_FUSED_STATIC = 2
 FLAG_NARROW_FFT = 4
 # bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
 DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (0xff << 16) | (0x7f << 24)
@@ -44,6 +45,7 @@ class AlBatch(ct.Structure):
         ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),
         ("yspec", ct.c_void_p), ("spatial", ct.c_void_p), ("partials", ct.c_void_p), ("event_stats", ct.c_void_p),
         ("event_scale", ct.c_void_p), ("clip_scale", ct.c_void_p),
+        ("xspec_zero_block", ct.c_int32), ("hspec_zero_block", ct.c_int32),
     ]
 
 
@@ -75,6 +77,8 @@ SYMBOLS = {
     "al_signal_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
+    "al_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
+    "al_mac_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_stats": (ct.c_int, [ct.POINTER(AlBatch), _S]),

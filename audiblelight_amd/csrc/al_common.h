@@ -107,5 +107,6 @@ __device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float 
 hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream);
+hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream);
 
 }  // namespace al

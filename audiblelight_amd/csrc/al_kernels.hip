@@ -106,6 +106,7 @@ __device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
+  if (ev.n_streams == 1 && (b.flags & AL_FLAG_FUSED_STATIC)) return;                               // k_mac_synthesis
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
@@ -854,6 +855,21 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   return AL_OK;
 }
 
+int al_fused_supported(const al_batch *b) {
+  if (check_batch(b)) return 0;
+  // the fused kernel addresses the signal spectra with 32-bit byte offsets from the workspace base
+  return b->log2_block == 13 && b->xspec_zero_block >= 0 && b->xspec_zero_block < 65535 && b->hspec_zero_block >= 0 &&
+         b->n_emitters > 0 && b->n_events > 0 && b->n_partitions < 32768;
+}
+
+int al_mac_synthesis(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  if (!(b->flags & AL_FLAG_FUSED_STATIC)) return AL_OK;
+  if (!al_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_STATIC needs B = 8192 and the zero blocks");
+  if (b->n_events <= 0 || b->max_blocks <= 0) return AL_OK;
+  return check_error(al::launch_mac_synthesis(b, (hipStream_t)stream), "k_mac_synthesis");
+}
+
 int al_block_synthesis(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->max_blocks <= 0) return AL_OK;
@@ -888,6 +904,7 @@ int al_render_batch(const al_batch *b, al_stream_t stream) {
   if ((rc = al_emitter_gains(b, stream))) return rc;
   if ((rc = al_signal_spectra(b, stream))) return rc;
   if ((rc = al_spectral_mac(b, stream))) return rc;
+  if ((rc = al_mac_synthesis(b, stream))) return rc;
   if ((rc = al_block_synthesis(b, stream))) return rc;
   return al_event_levels(b, stream);
 }

@@ -7,6 +7,7 @@
 
 #include "al_common.h"
 #include "al_fft.h"
+#include "al_fused.h"
 
 namespace al {
 
@@ -150,6 +151,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
   const int k0 = blockIdx.x * nb, c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (k0 >= ev.n_blocks) return;
+  if ((b.flags & AL_FLAG_FUSED_STATIC) && ev.n_streams == 1) return;  // k_mac_synthesis
   const int k1 = min(k0 + nb, ev.n_blocks);
   FftTwiddles<G> tw;
   load_fft_twiddles<G, 1>(tw, reinterpret_cast<const float2 *>(b.twiddle), tid0);
@@ -186,35 +188,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
       fft_regs_to_regs<G, 1>(v, s, tw, tid);
       // keep the alias-free second half of the 2B window: z[n], n in [M/2, M) = samples [B, 2B); those are
       // this thread's registers v[E/2..E-1] (n = tid + T*m), so the result never goes back through LDS
-      if (pair_ok && tbase + M <= ev.valid_len) {  // interior block (workgroup-uniform): unconditional pair stores
-        float *o = out + tbase + 2 * tid;
-#pragma unroll
-        for (int m = 0; m < H; ++m) {
-          const float2 z = v[H + m];
-          stream_store<16>(reinterpret_cast<float2 *>(o + 2 * T * m), z);
-          asum += fabsf(z.x) + fabsf(z.y);
-          amax = fmaxf(amax, fmaxf(fabsf(z.x), fabsf(z.y)));
-        }
-      } else {
-#pragma unroll
-        for (int m = 0; m < H; ++m) {
-          const int i = tid + T * m;  // complex index inside the kept half
-          const float2 z = v[H + m];
-          const int t = tbase + 2 * i;
-          const float x0 = t < ev.valid_len ? z.x : 0.f;
-          const float x1 = t + 1 < ev.valid_len ? z.y : 0.f;
-          if (t < ev.len) {
-            out[t] = x0;
-            asum += fabsf(x0);
-            amax = fmaxf(amax, fabsf(x0));
-          }
-          if (t + 1 < ev.len) {
-            out[t + 1] = x1;
-            asum += fabsf(x1);
-            amax = fmaxf(amax, fabsf(x1));
-          }
-        }
-      }
+      synth_store_block<G>(v, out, ev, tbase, pair_ok, tid, asum, amax);
       // a NaN or Inf anywhere makes the sum of magnitudes non-finite: one test per thread instead of one per sample
       bad = isfinite(asum) ? 0.f : 1.f;
       if (bad != 0.f) { asum = 0.f; amax = 0.f; }
@@ -262,6 +236,24 @@ hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream) {
   const dim3 grid(b->max_nj, b->n_streams);
   AL_DISPATCH_GEOM(b, k_signal_spectra, grid, *b);
+  return hipGetLastError();
+}
+
+hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream) {
+  constexpr int KT = AL_FUSED_KT;
+  const int64_t pairs = (int64_t)b->n_capsules * b->n_events, n_ktiles = (b->max_blocks + KT - 1) / KT;
+  const int64_t n_wg = (pairs + 7) / 8 * 8 * n_ktiles;   // see the workgroup mapping in k_mac_synthesis
+  if (n_wg > 0x7fffffff) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)n_wg);
+  const int P = b->n_partitions;
+  if (P <= 6) {
+    if (P == 6) hipLaunchKernelGGL((k_mac_synthesis<KT, 6, true>), grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((k_mac_synthesis<KT, 6, false>), grid, dim3(512), 0, stream, *b);
+  } else if (P % 12 == 0) {
+    hipLaunchKernelGGL((k_mac_synthesis<KT, 12, true>), grid, dim3(512), 0, stream, *b);
+  } else {
+    hipLaunchKernelGGL((k_mac_synthesis<KT, 12, false>), grid, dim3(512), 0, stream, *b);
+  }
   return hipGetLastError();
 }
 

@@ -245,15 +245,19 @@ class Renderer:
             streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
             wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
-            hspec=mem.empty(h_blocks * B * 2), xspec=mem.empty(x_blocks * B * 2),
+            # one extra, all-zero block behind each spectra workspace: al_mac_synthesis reads out-of-range blocks from it
+            hspec=mem.empty((h_blocks + 1) * B * 2), xspec=mem.empty((x_blocks + 1) * B * 2),
             yspec=mem.empty(y_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
             partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
             event_scale=mem.empty(len(plan.events)))
         if fold:
             bufs["clip_scale"] = mem.empty(len(plan.events))
         ptrs = {k: mem.ptr(v) for k, v in bufs.items()}
-        extra = [dict(hspec=mem.empty(h_blocks * B * 2), xspec=mem.empty(x_blocks * B * 2), yspec=mem.empty(y_blocks * B * 2))
-                 for _ in range(lanes - 1)]
+        extra = [dict(hspec=mem.empty((h_blocks + 1) * B * 2), xspec=mem.empty((x_blocks + 1) * B * 2),
+                      yspec=mem.empty(y_blocks * B * 2)) for _ in range(lanes - 1)]
+        for ws in [bufs] + extra:
+            ws["hspec"][h_blocks * B * 2:] = 0
+            ws["xspec"][x_blocks * B * 2:] = 0
         lane_ptrs = [ptrs] + [dict(ptrs, **{k: mem.ptr(v) for k, v in e.items()}) for e in extra]
         bufs["_lanes"] = extra
         descs = [_hip.AlBatch(
@@ -261,8 +265,15 @@ class Renderer:
             n_emitters=c["n_emitters"], ir_len=plan.ir_len, ir_stride_c=ir_strides[0], ir_stride_n=ir_strides[1],
             n_partitions=P, max_blocks=c["max_blocks"], max_nj=c["max_nj"], hop=plan.hop, event0=c["event0"],
             stream0=c["stream0"], emitter0=c["emitter0"], xspec_block0=c["xspec_block0"],
-            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(), **lane_ptrs[i % lanes])
+            yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(),
+            xspec_zero_block=x_blocks, hspec_zero_block=h_blocks, **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
+        # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes
+        # the Y round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
+        if os.environ.get("AL_FUSED", "0") == "1":
+            for desc in descs:
+                if self.lib.call("al_fused_supported", ct.byref(desc)):
+                    desc.flags |= _hip.FLAG_FUSED_STATIC
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
             pre = mem.upload(np.array([src.prescale for src in sources], dtype=np.float32))
             mode = mem.upload(np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32))
@@ -328,7 +339,8 @@ class PreparedBatch:
         for st in self._streams:
             st.wait_stream(cur)
         for i, desc in enumerate(self.descs):
-            lib.call("al_render_batch", ct.byref(desc), ct.c_void_p(self._streams[i % self.lanes].cuda_stream))
+            for name in self.stage_names(i):
+                lib.call(name, ct.byref(desc), ct.c_void_p(self._streams[i % self.lanes].cuda_stream))
         for st in self._streams:
             cur.wait_stream(st)
         return self.result()
@@ -337,17 +349,28 @@ class PreparedBatch:
         if self.lanes > 1 and stages is None and hasattr(self.renderer.mem, "torch"):
             return self._run_lanes()
         lib, stream = self.renderer.lib, self.renderer.mem.stream()
-        for desc in self.descs:
-            if stages is None:
-                lib.call("al_render_batch", ct.byref(desc), stream)
-            else:
-                for name in stages:
-                    lib.call(name, ct.byref(desc), stream)
+        for i, desc in enumerate(self.descs):
+            for name in (self.stage_names(i) if stages is None else stages):
+                lib.call(name, ct.byref(desc), stream)
         return self.result()
 
-    def stage_names(self) -> Sequence[str]:
-        """The C-ABI calls one pass of this batch makes, in order (bench.py times them one by one)."""
-        return self.STAGES
+    def stage_names(self, chunk: int = 0) -> Sequence[str]:
+        """The C-ABI calls one pass of a chunk makes, in order (bench.py times them one by one).  With
+        AL_FLAG_FUSED_STATIC the static events go through al_mac_synthesis; the unfused accumulate / synthesis are
+        launched only if the chunk has other events (moving: both; tiled dry clips: synthesis)."""
+        desc = self.descs[chunk]
+        if not (desc.flags & _hip.FLAG_FUSED_STATIC):
+            return self.STAGES
+        ev = self.plan.events[desc.event0: desc.event0 + desc.n_events]
+        moving, tiled = bool((ev["n_streams"] > 1).any()), bool((ev["n_streams"] == 0).any())
+        out = ["al_ir_spectra", "al_emitter_gains", "al_signal_spectra"]
+        if moving:
+            out.append("al_spectral_mac")
+        if bool((ev["n_streams"] == 1).any()):
+            out.append("al_mac_synthesis")
+        if moving or tiled:
+            out.append("al_block_synthesis")
+        return tuple(out + ["al_event_levels"])
 
     def run_stage(self, name: str, chunk: int = 0) -> None:
         self.renderer.lib.call(name, ct.byref(self.descs[chunk]), self.renderer.mem.stream())

@@ -33,6 +33,9 @@ extern "C" {
 #define AL_FLAG_NO_IR_NORM 1 /* IRs are already normalised: emitter_gain := 1 (time_invariant_convolution,
                                  time_variant_convolution called directly, synthesize.py:71,277) */
 
+#define AL_FLAG_FUSED_STATIC 2 /* static events (one emitter) go through al_mac_synthesis (accumulate + block synthesis in one
+                                  kernel, output spectra never written); al_spectral_mac / al_block_synthesis then skip
+                                  them.  Needs al_fused_supported(b) != 0. */
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
@@ -123,6 +126,8 @@ typedef struct {
   const float *clip_scale; /* optional (NULL = 1): per event scalar applied to the clip on top of al_stream.gain; written on
                               the device by al_clip_scales (peak normalisation + folded Gain/Invert, event.py:529-536), so
                               the clip's peak never travels to the host.  Indexed globally like event_scale. */
+  int32_t xspec_zero_block; /* index of an all-zero block inside xspec / hspec (-1: none).  al_mac_synthesis reads */
+  int32_t hspec_zero_block; /* out-of-range signal blocks / partitions from them instead of masking per lane. */
 } al_batch;
 
 /* Mixdown of one microphone (generate_scene_audio_from_events, synthesize.py:314-401). */
@@ -163,6 +168,10 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequenc
  * thread of the tile kernel); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
+/* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.
+ * al_fused_supported: 1 if this batch can use it (B = 8192, both zero blocks given, static events present). */
+int al_fused_supported(const al_batch *b);
+int al_mac_synthesis(const al_batch *b, al_stream_t stream);
 int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */
 /* The two halves of al_event_levels, for a scene whose capsules are sharded over several GPUs: every rank reduces
  * its own capsules into event_stats[e] = {sum|x|, max|x|, non-finite count, -}, the ranks all-reduce those E triples

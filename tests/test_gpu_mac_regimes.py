@@ -22,8 +22,50 @@ def gpu():
 
 @pytest.mark.parametrize("log2_block", [10, 11, 12, 13, 14])
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
-def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult):
-    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult)
+def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch):
+    """The tile kernels (k_spectral_mac + k_block_synthesis): the default path at every block size."""
+    monkeypatch.delenv("AL_FUSED", raising=False)
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False)
+
+
+@pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
+def test_fused_static_regimes(gpu, name, code, k_mult, p_mult, monkeypatch):
+    """k_mac_synthesis (B = 8192, opt-in with AL_FUSED=1: experimental, see profiles/r02_fused.txt): k-tiles of 4 blocks
+    with ragged last tiles, one and two partition tiles (PT = 6 / 12, full and ragged instantiations), clips shorter and
+    longer than the IR; every row against the oracle."""
+    monkeypatch.setenv("AL_FUSED", "1")
+    mr.run_static_case(gpu, 13, code, k_mult, p_mult, expect_fused=True)
+
+
+def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
+    """One batch with a static, a moving and a zero-emitter event at B = 8192: the fused kernel takes the static one,
+    the sliding-window accumulate + k_block_synthesis the moving one, k_block_synthesis the tiled one."""
+    import numpy as np
+
+    from audiblelight_amd import plan as planning
+    from oracle import synth_oracle as orc
+
+    monkeypatch.setenv("AL_FUSED", "1")
+    rng = np.random.default_rng(31)
+    sr, C, L, B = 48000, 3, 5 * 8192 + 100, 8192
+    specs, clips, irs, col = [], [], [], 0
+    for n_audio, n_emit in ((9 * B + 11, 1), (14 * B, 10), (3 * B + 5, 0), (2 * B - 3, 1)):
+        a = rng.standard_normal(n_audio).astype(np.float32)
+        clips.append(a / np.abs(a).max())
+        irs.append((rng.standard_normal((C, n_emit, L)) * np.exp(-np.arange(L) / (L / 5.0))).astype(np.float32))
+        specs.append(planning.EventSpec(n_samples=n_audio, n_emitters=n_emit, snr=float(rng.uniform(5, 30)), emitter0=col,
+                                        is_moving=n_emit > 1, duration=n_audio / sr))
+        col += n_emit
+    pl = planning.plan_batch(specs, C, L, sr, log2_block=13)
+    batch = gpu.prepare(pl, clips, np.concatenate(irs, axis=1))
+    assert mr.is_fused(batch) and list(batch.stage_names()) == ["al_ir_spectra", "al_emitter_gains", "al_signal_spectra",
+                                                                "al_spectral_mac", "al_mac_synthesis", "al_block_synthesis",
+                                                                "al_event_levels"]
+    res = batch.run()
+    res.check_finite()
+    for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
+        want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)["spatial"]
+        mr.check_event_rows(res, i, want)
 
 
 @pytest.mark.parametrize("log2_block", [10, 12, 13])
@@ -42,5 +84,11 @@ def test_cfg3_regime_all_rows(gpu):
 
 def test_cfg2_regime_all_rows(gpu):
     """cfg2's own regime at full length: B = 8192, K = 24, P = 12 (4 s clips, 2 s RIRs @ 48 kHz), 3 events x 5 capsules."""
-    res = mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3)
+    res = mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 24
+
+
+def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
+    """The same through the experimental k_mac_synthesis (AL_FUSED=1)."""
+    monkeypatch.setenv("AL_FUSED", "1")
+    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True)

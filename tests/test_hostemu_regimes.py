@@ -20,3 +20,10 @@ def test_emu_static_regimes(emu, name, code, k_mult, p_mult):
 @pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (12.6, 624), (24.2, 0)])
 def test_emu_moving_regimes(emu, p_mult, expect):
     mr.run_moving_case(emu, 10, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect, C=2, E=1)
+
+
+def test_emu_fused_static_kernel(emu, monkeypatch):
+    """k_mac_synthesis (B = 8192) under emulation: three k-tiles with a ragged last one, a partly empty partition tile,
+    the bin-0 fix-up, the LDS hand-over into the transform layout; every row against the oracle."""
+    monkeypatch.setenv("AL_FUSED", "1")
+    mr.run_static_case(emu, 13, 1121202, 9.3, 5.002, C=1, E=1, expect_fused=True)

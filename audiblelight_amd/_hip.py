@@ -56,6 +56,7 @@ class AlMix(ct.Structure):
         ("tile_ptr", ct.c_void_p), ("tile_events", ct.c_void_p), ("slot_src", ct.c_void_p), ("slot_len", ct.c_void_p),
         ("slot_start", ct.c_void_p), ("slot_count", ct.c_void_p), ("slot_rows", ct.c_void_p), ("slot_event", ct.c_void_p),
         ("spatial", ct.c_void_p), ("event_scale", ct.c_void_p), ("scene", ct.c_void_p),
+        ("ambience", ct.c_void_p), ("ambience_scale", ct.c_void_p),
     ]
 
 

@@ -344,10 +344,23 @@ __global__ __launch_bounds__(256) void k_mixdown(al_mix m) {
   constexpr int RUNS = 4;                       // m.tile == 4 * 256 * RUNS
   float4 acc[RUNS];
   const bool whole = (t_begin + m.tile <= m.n_samples) && ((m.n_samples & 3) == 0);  // workgroup-uniform
+  const float amb_scale = m.ambience ? *m.ambience_scale : 0.f;
+  const float *amb = m.ambience ? m.ambience + (int64_t)c * m.n_samples : row;
 #pragma unroll
   for (int r = 0; r < RUNS; ++r) {
     const int t = t_begin + 4 * (threadIdx.x + 256 * r);
     acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m.ambience) {   // the reference adds the ambience to the zeroed float32 buffer first (synthesize.py:335-356)
+      if (whole) {
+        const float4 nz = *reinterpret_cast<const float4 *>(amb + t);
+        acc[r] = make_float4(amb_scale * nz.x, amb_scale * nz.y, amb_scale * nz.z, amb_scale * nz.w);
+      } else {
+        if (t < m.n_samples) acc[r].x = amb_scale * amb[t];
+        if (t + 1 < m.n_samples) acc[r].y = amb_scale * amb[t + 1];
+        if (t + 2 < m.n_samples) acc[r].z = amb_scale * amb[t + 2];
+        if (t + 3 < m.n_samples) acc[r].w = amb_scale * amb[t + 3];
+      }
+    }
     if (m.accumulate) {
       if (whole) {
         acc[r] = *reinterpret_cast<const float4 *>(row + t);
@@ -914,6 +927,8 @@ int al_mixdown(const al_mix *m, al_stream_t stream) {
   if (m->tile != 4096) return fail(AL_E_BADARG, "mixdown tile must be 4096 samples");
   if (m->n_tiles != (m->n_samples + m->tile - 1) / m->tile) return fail(AL_E_BADARG, "n_tiles != ceil(n_samples / tile)");
   if (((uintptr_t)m->scene & 15) != 0) return fail(AL_E_BADARG, "scene buffer must be 16-byte aligned");
+  if (m->ambience && (!m->ambience_scale || m->accumulate || ((uintptr_t)m->ambience & 15) != 0))
+    return fail(AL_E_BADARG, "fused ambience needs ambience_scale, accumulate == 0 and a 16-byte aligned buffer");
   hipLaunchKernelGGL(al::k_mixdown, dim3(m->n_tiles, m->n_capsules), dim3(256), 0, (hipStream_t)stream, *m);
   return check_launch("k_mixdown");
 }

@@ -294,6 +294,9 @@ class Renderer:
         n = mix.n_capsules * mix.n_samples
         tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
                                         mix.slot_count, mix.slot_rows, mix.slot_event)]
+        # exactly one ambience and a fresh scene buffer (the normal case): added inside the mixdown kernel
+        fused = list(ambience) if (len(ambience) == 1 and scene is None) else []
+        ambience = [] if fused else list(ambience)
         accumulate = bool(ambience) or scene is not None
         zero_first = scene is None and bool(ambience)
         scene = mem.empty(n) if scene is None else scene
@@ -302,8 +305,9 @@ class Renderer:
                           accumulate=1 if accumulate else 0, tile_ptr=p(tabs[0]), tile_events=p(tabs[1]),
                           slot_src=p(tabs[2]), slot_len=p(tabs[3]), slot_start=p(tabs[4]), slot_count=p(tabs[5]),
                           slot_rows=p(tabs[6]), slot_event=p(tabs[7]), spatial=p(result.spatial),
-                          event_scale=p(result.event_scale), scene=p(scene))
-        return PreparedMix(self, mix, desc, scene, list(ambience), tabs + [result], zero_first)
+                          event_scale=p(result.event_scale), scene=p(scene),
+                          ambience=p(fused[0][0]) if fused else None, ambience_scale=p(fused[0][1]) if fused else None)
+        return PreparedMix(self, mix, desc, scene, list(ambience), tabs + [result] + fused, zero_first)
 
     # -- A11
     def mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()):

@@ -149,6 +149,9 @@ typedef struct {
   const float *spatial;
   const float *event_scale;
   float *scene;             /* (C, n_samples) float32 */
+  const float *ambience;       /* optional (NULL = none): (C, n_samples) normalised noise, added as *ambience_scale * noise */
+  const float *ambience_scale; /* in the same pass that mixes the events (synthesize.py:350-356 fused with :358-383): the */
+                               /* scene is written once instead of zeroed, read-modify-written, and read-modify-written again */
 } al_mix;
 
 const char *al_last_error(void);

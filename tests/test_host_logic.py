@@ -36,7 +36,7 @@ def test_cabi_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     assert _hip.EVENT_DTYPE.itemsize == 56 and _hip.STREAM_DTYPE.itemsize == 32
     assert ct.sizeof(_hip.AlBatch) == 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4   # 16 pointers, then the two zero-block indices
-    assert ct.sizeof(_hip.AlMix) == 6 * 4 + 11 * 8
+    assert ct.sizeof(_hip.AlMix) == 6 * 4 + 13 * 8
     assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
 
 

@@ -238,9 +238,12 @@ def main():
     if not emulate:
         torch.cuda.set_device(local_rank)
     backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path without N GPUs
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("AL_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL init with one rank
+    if use_dist:
         import torch.distributed as dist
 
+        if "MASTER_ADDR" not in os.environ:
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -309,7 +312,7 @@ def main():
 
     def barrier():
         device_sync()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         device_sync()
 
@@ -328,7 +331,7 @@ def main():
         for k in range(args.steps):
             step(ev[k])
         device_sync()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -382,7 +385,7 @@ def main():
                                      "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
     if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
         out["end_to_end_dropin"] = dropin_leg(scene, r, args.dropin)
-    if args.gather and world > 1:
+    if (args.gather and world > 1) or (use_dist and world == 1):
         from audiblelight_amd import distributed
 
         scene_t = mix.scene[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1)
@@ -405,7 +408,7 @@ def main():
                 workers = min(os.cpu_count() or 1, 64) if args.cpu_workers < 0 else args.cpu_workers
                 out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(scene, workers)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

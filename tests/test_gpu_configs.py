@@ -240,3 +240,23 @@ def test_hip_graph_replay_matches_eager(gpu):
     want = orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
                          keep_padded=False)["scene"]
     assert rel_rms(-gpu.mem.download(scene)[: want.size].reshape(want.shape), want) < TOL
+
+
+def test_bench_collectives_on_rccl_with_one_rank():
+    """bench.py's multi-rank plumbing on the REAL backend (RCCL init with device_id, barrier, MAX all-reduce of the step
+    time, the end-of-job gather) with the one GPU a test box has; the 2-rank logic itself is covered by the gloo test
+    (tests/test_host_logic.py::test_bench_gpus_flag_spawns_that_many_ranks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AL_BENCH_FORCE_DIST"] = "1"
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "20", "--cpu-events", "0",
+                          "--end-to-end", "0", "--dropin", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_per_rank"] == 4 * 4 * 240000
+    assert out["data"] == "synthetic" and out["value"] > 0

@@ -10,6 +10,7 @@ for seed in range(400):
     log2_block = int(rng.integers(10, 15))
     m = seed % 3
     os.environ["AL_EXTRA_FLAGS"] = str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)) if m == 1 else ("4" if m == 2 else "0")
+    os.environ["AL_FUSED"] = "1" if seed % 2 else "0"     # the experimental fused kernel takes the static events at B = 8192
     sr, C = 16000, int(rng.integers(1, 8))
     L = int(rng.integers(1, 3 << log2_block))
     specs, clips, irs, col = [], [], [], 0

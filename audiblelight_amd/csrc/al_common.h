@@ -76,6 +76,38 @@ __device__ __forceinline__ float2 stream_load(const float2 *p) {
   return *p;
 }
 
+// Blocks of M complex bins behind `base`, read 16 bytes per lane through a buffer descriptor: the block and column
+// offsets are SCALAR (soffset), the only vector register is the lane's byte offset.  `poison` makes every lane's
+// offset fall outside the descriptor's range, for which the hardware returns 0.
+struct SpectraView {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __amdgpu_buffer_rsrc_t rsrc;
+  __device__ __forceinline__ SpectraView(const float2 *base, int n_blocks, int M)
+      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, n_blocks * M * 8, 0x00020000)) {}
+  __device__ __forceinline__ float4 load(int byte_offset, int lane_bytes) const {
+    typedef int v4i __attribute__((ext_vector_type(4)));
+    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_offset, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+  }
+#else
+  const char *base;
+  int64_t n_bytes;
+  __device__ __forceinline__ SpectraView(const float2 *b, int n, int M)
+      : base(reinterpret_cast<const char *>(b)), n_bytes((int64_t)n * M * 8) {}
+  __device__ __forceinline__ float4 load(int byte_offset, int lane_bytes) const {
+    if ((unsigned)lane_bytes >= (uint64_t)n_bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
+    return *reinterpret_cast<const float4 *>(base + (unsigned)byte_offset + lane_bytes);
+  }
+#endif
+};
+constexpr int SPECTRA_POISON = (int)0x80000000u;
+
+__device__ __forceinline__ void pipeline_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ------------------------------------------------------------------ block-wide reductions
 // sum / max / sum over the workgroup; result valid in thread 0.  `scratch` holds 3 floats per wave.
 __device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float &c_sum, float *scratch, int tid,

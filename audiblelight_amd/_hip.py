@@ -18,6 +18,7 @@ AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
 FLAG_FUSED_STATIC = 2
+FLAG_SPLIT_SPECTRA = 32
 FLAG_NARROW_FFT = 4
 # bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
 DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (0xff << 16) | (0x7f << 24)

@@ -244,11 +244,12 @@ struct PassTwiddles {
   float2 a[NB], c[NB], d[NB];
 };
 
-template <class G, int DIR, int PASS>
+// TS: the table was made for TS * G::M points (tw[k] = exp(-i*pi*k / (TS*M))); every index is scaled by TS.
+template <class G, int DIR, int PASS, int TS = 1>
 __device__ __forceinline__ void load_pass_twiddles(PassTwiddles<G, PASS> &t, const float2 *__restrict__ tw, int tid) {
   if constexpr (PASS > 0 && PASS < G::NPASSES) {
     constexpr int R = G::radix(PASS), NS = G::ns(PASS), NB = G::E / R;
-    constexpr int STEP = 2 * G::M / (NS * R);  // tw[k*STEP] = exp(-2*pi*i*k/(NS*R))
+    constexpr int STEP = TS * 2 * G::M / (NS * R);  // tw[k*STEP] = exp(-2*pi*i*k/(NS*R))
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       const int k = (tid + G::T * b) & (NS - 1);
@@ -308,13 +309,13 @@ struct FftTwiddles {
   }
 };
 
-template <class G, int DIR>
+template <class G, int DIR, int TS = 1>
 __device__ __forceinline__ void load_fft_twiddles(FftTwiddles<G> &t, const float2 *__restrict__ tw, int tid) {
   static_assert(G::NPASSES <= 4, "FftTwiddles holds three twiddled passes");
-  load_pass_twiddles<G, DIR, 1>(t.p1, tw, tid);
-  load_pass_twiddles<G, DIR, 2>(t.p2, tw, tid);
-  load_pass_twiddles<G, DIR, 3>(t.p3, tw, tid);
-  t.w0 = tw[tid];
+  load_pass_twiddles<G, DIR, 1, TS>(t.p1, tw, tid);
+  load_pass_twiddles<G, DIR, 2, TS>(t.p2, tw, tid);
+  load_pass_twiddles<G, DIR, 3, TS>(t.p3, tw, tid);
+  t.w0 = tw[tid * TS];
 }
 
 // Packing-step factors: tw[tid + T*m] = tw[tid] * exp(-i*pi*m/E) (T/M = 1/E), the second factor a constant.

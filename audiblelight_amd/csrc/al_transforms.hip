@@ -206,7 +206,23 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
   }
 }
 
+}  // namespace al
+#include "al_split.h"
+namespace al {
+
 // ------------------------------------------------------------------ launchers
+#define AL_DISPATCH_SPLIT(b, KERNEL, GRID, ...)                                                                          \
+  do {                                                                                                                  \
+    switch ((b)->log2_block) {                                                                                          \
+      case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, dim3(FftGeom<10, 16>::T), 0, stream, __VA_ARGS__); break;         \
+      case 12: hipLaunchKernelGGL((KERNEL<12>), GRID, dim3(FftGeom<11, 16>::T), 0, stream, __VA_ARGS__); break;         \
+      case 13: hipLaunchKernelGGL((KERNEL<13>), GRID, dim3(FftGeom<12, 16>::T), 0, stream, __VA_ARGS__); break;         \
+      case 14: hipLaunchKernelGGL((KERNEL<14>), GRID, dim3(FftGeom<13, 16>::T), 0, stream, __VA_ARGS__); break;         \
+      default: return hipErrorInvalidValue;                                                                             \
+    }                                                                                                                   \
+  } while (0)
+static bool use_split(const al_batch *b) { return (b->flags & AL_FLAG_SPLIT_SPECTRA) && b->log2_block >= 11; }
+
 #define AL_DISPATCH_GEOM(b, KERNEL, GRID, ...)                                                                        \
   do {                                                                                                                \
     const bool wide = (b)->log2_block >= 13 && !((b)->flags & AL_FLAG_NARROW_FFT);                                      \
@@ -227,6 +243,11 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
   } while (0)
 
 hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
+  if (use_split(b)) {
+    const dim3 grid(b->n_partitions, b->n_capsules, b->n_emitters);
+    AL_DISPATCH_SPLIT(b, k_ir_spectra_split, grid, *b);
+    return hipGetLastError();
+  }
   const int nb = max(1, (b->flags >> 24) & 0x7f);  // AL_FLAG_IR_RUN(n): partitions per workgroup
   const dim3 grid((b->n_partitions + nb - 1) / nb, b->n_capsules, b->n_emitters);
   AL_DISPATCH_GEOM(b, k_ir_spectra, grid, *b, nb);
@@ -235,6 +256,10 @@ hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
 
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream) {
   const dim3 grid(b->max_nj, b->n_streams);
+  if (use_split(b)) {
+    AL_DISPATCH_SPLIT(b, k_signal_spectra_split, grid, *b);
+    return hipGetLastError();
+  }
   AL_DISPATCH_GEOM(b, k_signal_spectra, grid, *b);
   return hipGetLastError();
 }
@@ -258,6 +283,11 @@ hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream) {
 }
 
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream) {
+  if (use_split(b)) {
+    const dim3 grid(b->max_blocks, b->n_capsules, b->n_events);
+    AL_DISPATCH_SPLIT(b, k_block_synthesis_split, grid, *b);
+    return hipGetLastError();
+  }
   const int nb = max(1, (b->flags >> 16) & 0xff);  // AL_FLAG_SYNTH_RUN(n): blocks per workgroup
   const dim3 grid((b->max_blocks + nb - 1) / nb, b->n_capsules, b->n_events);
   AL_DISPATCH_GEOM(b, k_block_synthesis, grid, *b, nb);

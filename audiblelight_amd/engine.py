@@ -268,9 +268,16 @@ class Renderer:
             yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(),
             xspec_zero_block=x_blocks, hspec_zero_block=h_blocks, **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
+        # Split-layout transforms (csrc/al_split.h): every window as two half-size FFTs.  Default at B = 8192, where it is
+        # 5 % faster per scene (profiles/r02_split.txt); slower at B = 4096 / 16384.  AL_SPLIT=0 / 1 forces it off / on.
+        fused = os.environ.get("AL_FUSED", "0") == "1"
+        want_split = os.environ.get("AL_SPLIT", "1" if plan.log2_block == 13 and not fused else "0") == "1"
+        if want_split and plan.log2_block >= 11:
+            for desc in descs:
+                desc.flags |= _hip.FLAG_SPLIT_SPECTRA
         # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes
         # the Y round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
-        if os.environ.get("AL_FUSED", "0") == "1":
+        if fused and not (want_split and plan.log2_block >= 11):
             for desc in descs:
                 if self.lib.call("al_fused_supported", ct.byref(desc)):
                     desc.flags |= _hip.FLAG_FUSED_STATIC

@@ -36,6 +36,9 @@ extern "C" {
 #define AL_FLAG_FUSED_STATIC 2 /* static events (one emitter) go through al_mac_synthesis (accumulate + block synthesis in one
                                   kernel, output spectra never written); al_spectral_mac / al_block_synthesis then skip
                                   them.  Needs al_fused_supported(b) != 0. */
+#define AL_FLAG_SPLIT_SPECTRA 32 /* spectra in the split layout of csrc/al_split.h (even bins | odd bins, every window transformed
+                                    as two half-size FFTs); all of al_ir_spectra / al_signal_spectra / al_block_synthesis must
+                                    see the same setting; the accumulate does not care.  B >= 2048; excludes AL_FLAG_FUSED_STATIC */
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */

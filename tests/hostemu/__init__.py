@@ -14,7 +14,7 @@ SRCS = [os.path.join(CSRC, "al_kernels.hip"), os.path.join(CSRC, "al_transforms.
 
 def build(sanitize: bool = False) -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    deps = SRCS + [os.path.join(CSRC, f) for f in ("al_fft.h", "al_bigfft.h", "al_common.h")] + [
+    deps = SRCS + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):
         return LIB

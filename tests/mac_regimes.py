@@ -41,13 +41,19 @@ def check_event_rows(res, i, want, tol=TOL):
     assert np.max(np.abs(got - want)) <= 10 * tol * np.max(np.abs(want))
 
 
+def is_split(batch, chunk=0):
+    from audiblelight_amd import _hip
+
+    return bool(batch.descs[chunk].flags & _hip.FLAG_SPLIT_SPECTRA)
+
+
 def is_fused(batch, chunk=0):
     from audiblelight_amd import _hip
 
     return bool(batch.descs[chunk].flags & _hip.FLAG_FUSED_STATIC)
 
 
-def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None):
+def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None, expect_split=None):
     """``expect_fused``: None = whatever the library picks (B = 8192: al_mac_synthesis, csrc/al_fused.h), True / False =
     assert it (callers force the unfused kernels with AL_FUSED=0 so that their dispatch branches stay pinned too)."""
     B = 1 << log2_block
@@ -65,6 +71,8 @@ def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0
     batch = renderer.prepare(pl, clips, mic_ir)
     got_code, moving = mac_codes(renderer, batch)
     assert got_code == code and moving == 0, (got_code, moving)
+    if expect_split is not None:
+        assert is_split(batch) == expect_split
     if expect_fused is not None:
         assert is_fused(batch) == expect_fused
         assert ("al_mac_synthesis" in batch.stage_names()) == expect_fused

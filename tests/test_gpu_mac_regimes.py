@@ -25,7 +25,7 @@ def gpu():
 def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch):
     """The tile kernels (k_spectral_mac + k_block_synthesis): the default path at every block size."""
     monkeypatch.delenv("AL_FUSED", raising=False)
-    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False)
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block == 13))
 
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
@@ -34,7 +34,7 @@ def test_fused_static_regimes(gpu, name, code, k_mult, p_mult, monkeypatch):
     with ragged last tiles, one and two partition tiles (PT = 6 / 12, full and ragged instantiations), clips shorter and
     longer than the IR; every row against the oracle."""
     monkeypatch.setenv("AL_FUSED", "1")
-    mr.run_static_case(gpu, 13, code, k_mult, p_mult, expect_fused=True)
+    mr.run_static_case(gpu, 13, code, k_mult, p_mult, expect_fused=True, expect_split=False)
 
 
 def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
@@ -73,6 +73,51 @@ def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
                          ids=["P5", "P12", "P13", "P24", "P25_tile_kernel"])
 def test_moving_regimes(gpu, log2_block, p_mult, expect):
     mr.run_moving_case(gpu, log2_block, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect)
+
+
+@pytest.mark.parametrize("log2_block,split", [(11, "1"), (12, "1"), (13, "0"), (13, "1"), (14, "1")])
+def test_transform_layouts(gpu, monkeypatch, log2_block, split):
+    """Both spectrum layouts of the FFT kernels: the split layout (csrc/al_split.h: every window as two half-size
+    transforms, default at B = 8192) at every block size it is built for, and the one-transform kernels at B = 8192 with
+    AL_SPLIT=0 (they stay the default elsewhere and are what every other block size in this file runs).  Static events
+    with a ragged last partition / block, moving events and a tiled dry clip, every row against the oracle."""
+    import numpy as np
+
+    from audiblelight_amd import plan as planning
+    from oracle import synth_oracle as orc
+
+    monkeypatch.setenv("AL_SPLIT", split)
+    B = 1 << log2_block
+    rng = np.random.default_rng(40 + log2_block)
+    sr, C, L = 48000, 3, int(2.3 * B) + 7
+    specs, clips, irs, col = [], [], [], 0
+    for n_audio, n_emit in ((int(4.6 * B) + 3, 1), (7 * B, 6), (B + 5, 0), (B // 2 - 3, 1)):
+        a = rng.standard_normal(n_audio).astype(np.float32)
+        clips.append(a / np.abs(a).max())
+        irs.append((rng.standard_normal((C, n_emit, L)) * np.exp(-np.arange(L) / (L / 5.0))).astype(np.float32))
+        specs.append(planning.EventSpec(n_samples=n_audio, n_emitters=n_emit, snr=float(rng.uniform(5, 30)), emitter0=col,
+                                        is_moving=n_emit > 1, duration=n_audio / sr))
+        col += n_emit
+    pl = planning.plan_batch(specs, C, L, sr, log2_block=log2_block)
+    batch = gpu.prepare(pl, clips, np.concatenate(irs, axis=1))
+    assert mr.is_split(batch) == (split == "1")
+    res = batch.run()
+    res.check_finite()
+    for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
+        want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)["spatial"]
+        mr.check_event_rows(res, i, want)
+
+
+def test_default_layout_per_block_size(gpu, monkeypatch):
+    from audiblelight_amd import plan as planning
+    import numpy as np
+
+    monkeypatch.delenv("AL_SPLIT", raising=False)
+    monkeypatch.delenv("AL_FUSED", raising=False)
+    for lb in (10, 12, 13, 14):
+        pl = planning.plan_batch([planning.EventSpec(n_samples=3000, n_emitters=1, snr=5.0)], 2, 500, 48000, log2_block=lb)
+        batch = gpu.prepare(pl, [np.zeros(3000, np.float32)], np.zeros((2, 1, 500), np.float32))
+        assert mr.is_split(batch) == (lb == 13)
 
 
 def test_cfg3_regime_all_rows(gpu):

@@ -27,3 +27,12 @@ def test_emu_fused_static_kernel(emu, monkeypatch):
     the bin-0 fix-up, the LDS hand-over into the transform layout; every row against the oracle."""
     monkeypatch.setenv("AL_FUSED", "1")
     mr.run_static_case(emu, 13, 1121202, 9.3, 5.002, C=1, E=1, expect_fused=True)
+
+
+def test_emu_split_layout_transforms(emu, monkeypatch):
+    """csrc/al_split.h under emulation (B = 2048, the smallest it is built for): even / odd half spectra, the LDS layout
+    change of the difference signal, the combine of the two half-size inverses; static (two k-tiles, ragged partitions)
+    and moving events, every row against the oracle."""
+    monkeypatch.setenv("AL_SPLIT", "1")
+    mr.run_static_case(emu, 11, 1121202, 10.0006, 5.002, C=2, E=1, expect_split=True)
+    mr.run_moving_case(emu, 11, 4.3, n_irs=10, k_mult=14.2, expect_moving=612, C=1, E=1)

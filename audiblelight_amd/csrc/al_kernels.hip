@@ -64,6 +64,24 @@ __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b, int mode, int 
 // costs KT+2*PT-1 loads for KT*PT complex FMAs (static register indices throughout).
 // Bin 0 packs (DC, Nyquist): two independent real products.
 // VB = bins per thread (1: float2 accesses, 2: float4 accesses of two adjacent bins).
+// a += x * h (complex) as TWO v_pk_fma_f32 whose operand halves are picked by op_sel / negated by neg_lo: no swizzled
+// copies of x or h exist in registers (left to itself hipcc keeps (x.x, x.x) and (-x.y, x.y) for every resident spectrum,
+// doubling its register cost: profiles/r01_mac_variants.txt).
+__device__ __forceinline__ void cfma_packed(float2 &a, const float2 &x, const float2 &h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  v2f av = {a.x, a.y};
+  const v2f xv = {x.x, x.y}, hv = {h.x, h.y};
+  // lo: x.x*h.x + a.x          hi: x.x*h.y + a.y
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1]" : "+v"(av) : "v"(xv), "v"(hv));
+  // lo: -x.y*h.y + a.x         hi: x.y*h.x + a.y
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(av) : "v"(xv), "v"(hv));
+  a = make_float2(av.x, av.y);
+#else
+  cfma(a, x, h);
+#endif
+}
+
 template <int VB> struct BinVec;
 template <> struct BinVec<1> {
   float2 a;
@@ -91,7 +109,17 @@ template <> struct BinVec<2> {
     if (BIN0 && packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma(a, x.a, h.a);
     cfma(c, x.c, h.c);
   }
+  template <bool BIN0>
+  __device__ __forceinline__ void fma_packed(const BinVec &x, const BinVec &h, bool packed) {
+    if (BIN0 && packed) { a.x = fmaf(x.a.x, h.a.x, a.x); a.y = fmaf(x.a.y, h.a.y, a.y); } else cfma_packed(a, x.a, h.a);
+    cfma_packed(c, x.c, h.c);
+  }
 };
+
+// k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
+__host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 12 && b.log2_block >= 9;
+}
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
 // Workgroups of one bin tile share blockIdx.x, hence (round-robin dispatch) an XCD and its L2, and the tiles of one
@@ -106,7 +134,7 @@ __device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
-  if (ev.n_streams == 1 && (b.flags & AL_FLAG_FUSED_STATIC)) return;                               // k_mac_synthesis
+  if (ev.n_streams == 1 && ((b.flags & AL_FLAG_FUSED_STATIC) || static_mac_active(b))) return;     // k_mac_synthesis / k_spectral_mac_static
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
@@ -191,6 +219,102 @@ template <int KT, int PT, int VB, bool KSPLIT = false>
 __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
   if (blockIdx.x == 0 && threadIdx.x < 64) spectral_mac_body<KT, PT, VB, KSPLIT, true>(b);
   else spectral_mac_body<KT, PT, VB, KSPLIT, false>(b);
+}
+
+// ------------------------------------------------------------------ 4a. accumulate for static events, capsule loop
+// A static event has ONE stream, so the signal blocks a (k-tile, bin tile) needs -- the KT+PT-1 blocks on its anti-
+// diagonals -- are the same for every capsule.  One workgroup therefore owns (event, k-tile, bin tile) and LOOPS over the
+// capsules with that window held in registers (loaded once, already multiplied by the emitter gain and zeroed where
+// k - p leaves the clip: no per-capsule masks or gain multiplies).  What this buys over one workgroup per capsule
+// (profiles/r02_mac.txt): the signal spectra leave L2 once instead of C times, the workgroup start-up (three dependent
+// table reads) and the dispatch of 32x as many workgroups disappear, and because nothing waits on X any more the
+// partition spectrum h[p] of the NEXT capsule is requested the moment the last product with h[p] of this one has been
+// issued -- the H stream, the FMAs and the Y stores of consecutive capsules overlap inside one wave.
+// MASKH: the partition count is not a multiple of PT, so a tile can hold partitions that do not exist (read clamped,
+// zeroed by a uniform multiply); with P % PT == 0 every h[pp] is a real partition and no mask exists in the loop.
+// NKTW: k-tiles per workgroup (256 threads each).  Two k-tiles of one (event, bin tile) read the SAME partition spectra;
+// in one workgroup, kept in step by a barrier per capsule, the second read of every line is an L1 hit on the same CU
+// instead of a second trip to L2 / HBM by another workgroup that may have drifted away.
+template <int KT, int PT, bool BIN0, bool MASKH, int NKTW>
+__device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
+  using V = BinVec<2>;
+  constexpr int NJ = KT + PT - 1;
+  const int M = 1 << b.log2_block;
+  const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8;
+  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int n_cs = gridDim.z / b.n_events;                      // capsule ranges per event (small batches)
+  const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
+  const al_event ev = b.events[b.event0 + e];
+  if (ev.n_streams != 1) return;                                // moving events: k_spectral_mac / k_spectral_mac_moving
+  const int K = ev.n_blocks, P = b.n_partitions, C = b.n_capsules;
+  const int k0 = (blockIdx.y * NKTW + sub) * KT;
+  if (NKTW == 1 && k0 >= K) return;
+  const bool active = k0 < K;                                   // NKTW > 1: an idle half still joins the barriers
+  const int c_begin = (int)((int64_t)cs * C / n_cs), c_end = (int)((int64_t)(cs + 1) * C / n_cs);
+  const al_stream st = b.streams[ev.stream0];
+  const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
+  const int plo = max(0, k0 - jhi + 1), phi = min(P - 1, k0 + KT - 1 - jlo);
+  const bool packed = (f == 0);
+  const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
+  const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + f;
+  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + k0) * M + f;
+  const float g = b.emitter_gain[st.emitter];
+  const bool single = phi - plo < PT;                           // one partition tile: the window survives the capsule loop
+  // (plo > phi cannot happen for a static event, whose signal blocks are [0, K): plo = 0 <= phi)
+
+  V xw[NJ];
+  auto load_window = [&](int p0) {                              // xw[jj] = g * X[k0 - p0 - (PT-1) + jj], 0 outside the clip
+    const int jbase = k0 - p0 - (PT - 1);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int j = jbase + jj;
+      xw[jj] = V::load(X + (int64_t)min(max(j, jlo), jhi - 1) * M);
+      xw[jj].scale((j >= jlo && j < jhi) ? g : 0.f);
+    }
+  };
+  auto h_load = [&](int c, int p) {
+    V v = V::load(H + ((int64_t)c * P + min(p, P - 1)) * M);
+    if constexpr (MASKH) v.scale(p <= phi ? 1.f : 0.f);        // uniform
+    return v;
+  };
+  V h[PT];
+  if (single && active) {
+    load_window(plo);
+#pragma unroll
+    for (int pp = 0; pp < PT; ++pp) h[pp] = h_load(c_begin, plo + pp);
+  }
+  for (int c = c_begin; c < c_end; ++c) {
+    if (NKTW > 1) __syncthreads();                              // both k-tiles start the capsule together
+    if (!active) continue;
+    V acc[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
+    const int cn = min(c + 1, c_end - 1);                       // capsule whose spectra are requested during this one
+    for (int p0 = plo; p0 <= phi; p0 += PT) {
+      if (!single) {
+        load_window(p0);
+#pragma unroll
+        for (int pp = 0; pp < PT; ++pp) h[pp] = h_load(c, p0 + pp);
+      }
+      static_for<PT>([&](auto pp_c) {
+        constexpr int pp = decltype(pp_c)::value;
+        static_for<KT>([&](auto kk_c) {
+          constexpr int kk = decltype(kk_c)::value;
+          acc[kk].template fma_packed<BIN0>(xw[kk + (PT - 1) - pp], h[pp], packed);   // X[k0 + kk - (p0 + pp)]
+        });
+        if (single) h[pp] = h_load(cn, plo + pp);                // h[pp] is free: fetch the next capsule's
+      });
+    }
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk)
+      if (k0 + kk < K) acc[kk].store(Y + ((int64_t)c * K + kk) * M);
+  }
+}
+
+template <int KT, int PT, bool MASKH, int NKTW>
+__global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch b) {
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_body<KT, PT, true, MASKH, NKTW>(b);
+  else spectral_mac_static_body<KT, PT, false, MASKH, NKTW>(b);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events
@@ -784,6 +908,10 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream) {
 
 // Which instantiations al_spectral_mac launches for a batch.  Static code = 1000000*KSPLIT + 10000*KT + 100*PT + VB of
 // k_spectral_mac<KT,PT,VB,KSPLIT>; moving code = 100*NJW + PT of k_spectral_mac_moving<NJW,PT,1> (0: not launched).
+static bool static_pair(const al_batch *b) {   // two k-tiles per workgroup (flags bit 12: experiment switch, one per workgroup)
+  return (b->max_blocks + 11) / 12 > 1 && !(b->flags & (1 << 12));
+}
+
 static void pick_mac(const al_batch *b, int32_t *static_code, int32_t *moving_code) {
   const int variant = (b->flags >> 8) & 15;
   const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
@@ -815,6 +943,12 @@ int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *mo
   if (int rc = check_batch(b)) return rc;
   if (!static_code || !moving_code) return fail(AL_E_BADARG, "null output");
   pick_mac(b, static_code, moving_code);
+  // one-emitter events through k_spectral_mac_static<12, PT, MASKH, NKTW>: 3000000 + 10000*12 + 100*PT + 10*MASKH + NKTW
+  // (the tile kernel pick_mac names then only sees multi-emitter events, if the batch has any)
+  if (al::static_mac_active(*b)) {
+    const int P = b->n_partitions, PT = P <= 6 ? 6 : 12;
+    *static_code = 3000000 + 120000 + 100 * PT + 10 * (P % PT != 0 ? 1 : 0) + (static_pair(b) ? 2 : 1);
+  }
   return AL_OK;
 }
 
@@ -826,6 +960,32 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
   int32_t code, moving;
   pick_mac(b, &code, &moving);
   const int bins = 1 << b->log2_block;
+  if (al::static_mac_active(*b)) {
+    // enough workgroups to fill the chip: split the capsule loop for small batches
+    const int n_ktiles = (b->max_blocks + 11) / 12, base = (bins / 512) * n_ktiles * b->n_events;
+    int n_cs = 1;
+    while (n_cs < b->n_capsules && base * n_cs < 1024) n_cs *= 2;
+    if (n_cs > b->n_capsules) n_cs = b->n_capsules;
+    const int P = b->n_partitions;
+    const bool pair = static_pair(b);
+    const dim3 grid(bins / 512, pair ? (n_ktiles + 1) / 2 : n_ktiles, b->n_events * n_cs);
+#define AL_STATIC(PT_, MASK_) \
+    do { \
+      if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, MASK_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
+      else hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, MASK_, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b); \
+    } while (0)
+    if (P <= 6) {
+      if (P == 6) AL_STATIC(6, false);
+      else AL_STATIC(6, true);
+    } else if (P % 12 == 0) {
+      AL_STATIC(12, false);
+    } else {
+      AL_STATIC(12, true);
+    }
+#undef AL_STATIC
+    if (int rc = check_launch("k_spectral_mac_static")) return rc;
+    if (b->flags & AL_FLAG_ONLY_STATIC) return AL_OK;   // no event is left for the tile / sliding-window kernels
+  }
 #define AL_MAC(KT_, PT_, VB_) \
   case 10000 * KT_ + 100 * PT_ + VB_: \
     hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \

@@ -281,6 +281,17 @@ class Renderer:
             for desc in descs:
                 if self.lib.call("al_fused_supported", ct.byref(desc)):
                     desc.flags |= _hip.FLAG_FUSED_STATIC
+        # One-emitter (static) events: the capsule-loop accumulate (k_spectral_mac_static), default wherever the partitions
+        # fit its register tile (P <= 12: -7 % on cfg2's accumulate, -14 % on cfg4's; profiles/r02_mac.txt).
+        if os.environ.get("AL_STATIC_MAC", "1") == "1" and plan.n_partitions <= 12:
+            for desc in descs:
+                if desc.flags & _hip.FLAG_FUSED_STATIC:
+                    continue
+                ev = plan.events[desc.event0: desc.event0 + desc.n_events]
+                if (ev["n_streams"] == 1).any():
+                    desc.flags |= _hip.FLAG_STATIC_MAC
+                    if not (ev["n_streams"] > 1).any():
+                        desc.flags |= _hip.FLAG_ONLY_STATIC
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
             pre = mem.upload(np.array([src.prescale for src in sources], dtype=np.float32))
             mode = mem.upload(np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32))

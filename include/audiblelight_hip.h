@@ -39,6 +39,10 @@ extern "C" {
 #define AL_FLAG_SPLIT_SPECTRA 32 /* spectra in the split layout of csrc/al_split.h (even bins | odd bins, every window transformed
                                     as two half-size FFTs); all of al_ir_spectra / al_signal_spectra / al_block_synthesis must
                                     see the same setting; the accumulate does not care.  B >= 2048; excludes AL_FLAG_FUSED_STATIC */
+#define AL_FLAG_STATIC_MAC 64   /* al_spectral_mac: static (one-emitter) events through k_spectral_mac_static (one workgroup per
+                                   (event, k-tile, bin tile) looping over the capsules); the tile kernels skip them */
+#define AL_FLAG_ONLY_STATIC 128 /* with AL_FLAG_STATIC_MAC: the batch has no multi-emitter event, so the other accumulate
+                                   kernels are not launched at all (the host knows the event table, the library does not) */
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
@@ -170,8 +174,9 @@ int al_emitter_gains(const al_batch *b, al_stream_t stream);   /* A1 normalize_i
 int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 envelope + block spectra */
 int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
 /* Which kernel instantiations al_spectral_mac launches for this batch (no launch; used by the parity tests to assert
- * the regime they cover).  *static_code = 1000000*KSPLIT + 10000*KT + 100*PT + VB (k-tile, partition tile, bins per
- * thread of the tile kernel); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
+ * the regime they cover).  *static_code = the kernel that takes one-emitter events: 1000000*KSPLIT + 10000*KT + 100*PT + VB
+ * (k-tile, partition tile, bins per thread of the tile kernel), or 3120000 + 100*PT + 10*MASKH + NKTW for the capsule-loop
+ * kernel k_spectral_mac_static (AL_FLAG_STATIC_MAC and at most 12 partitions); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 /* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.

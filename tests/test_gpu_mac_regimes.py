@@ -23,9 +23,30 @@ def gpu():
 @pytest.mark.parametrize("log2_block", [10, 11, 12, 13, 14])
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
 def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch):
-    """The tile kernels (k_spectral_mac + k_block_synthesis): the default path at every block size."""
+    """The tile kernels (k_spectral_mac + k_block_synthesis): AL_STATIC_MAC=0 keeps their dispatch branches reachable for
+    static events (they are the default for more than 12 partitions and for multi-emitter events)."""
+    monkeypatch.setenv("AL_STATIC_MAC", "0")
     monkeypatch.delenv("AL_FUSED", raising=False)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block == 13))
+
+
+STATIC_LOOP_CASES = [   # (name, expected code 3120000 + 100*PT + 10*MASKH + NKTW, K multiple, P multiple, capsules, events)
+    ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
+    ("pair_ragged_ktile_masked", 3121212, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9: masked partitions
+    ("one_ktile_full6", 3120601, 10.0006, 5.002, 4, 3),        # K = 11, P = 6 = PT
+    ("one_ktile_masked6", 3120611, 6.5, 2.5, 3, 1),            # K = 7, P = 3 < PT; one event: capsule ranges split
+    ("three_ktiles_idle_half", 3121202, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles, the last workgroup has an idle half
+]
+
+
+@pytest.mark.parametrize("log2_block", [10, 13])
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", STATIC_LOOP_CASES, ids=[c[0] for c in STATIC_LOOP_CASES])
+def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
+    """k_spectral_mac_static (default for one-emitter events with at most 12 partitions): every instantiation, ragged
+    tiles, the capsule-range split of small batches; every row against the oracle."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_FUSED", raising=False)
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
 
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
@@ -129,11 +150,18 @@ def test_cfg3_regime_all_rows(gpu):
 
 def test_cfg2_regime_all_rows(gpu):
     """cfg2's own regime at full length: B = 8192, K = 24, P = 12 (4 s clips, 2 s RIRs @ 48 kHz), 3 events x 5 capsules."""
-    res = mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False)
+    res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False, expect_split=True)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 24
+
+
+def test_cfg2_regime_all_rows_tile_kernels(gpu, monkeypatch):
+    """The same through k_spectral_mac<12,12,2,KSPLIT> and the one-transform FFT kernels (round 1's path)."""
+    monkeypatch.setenv("AL_STATIC_MAC", "0")
+    monkeypatch.setenv("AL_SPLIT", "0")
+    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False, expect_split=False)
 
 
 def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
     """The same through the experimental k_mac_synthesis (AL_FUSED=1)."""
     monkeypatch.setenv("AL_FUSED", "1")
-    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True)
+    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True, expect_split=False)

@@ -13,8 +13,17 @@ def emu():
 
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
-def test_emu_static_regimes(emu, name, code, k_mult, p_mult):
+def test_emu_static_regimes(emu, name, code, k_mult, p_mult, monkeypatch):
+    monkeypatch.setenv("AL_STATIC_MAC", "0")   # the tile kernels
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=2)
+
+
+@pytest.mark.parametrize("code,k_mult,p_mult,C,E", [(3121212, 17.3, 8.6, 3, 1), (3120601, 10.0006, 5.002, 2, 2), (3120611, 6.5, 2.5, 3, 1)])
+def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeypatch):
+    """k_spectral_mac_static under emulation: paired k-tiles with a half-empty second tile and masked partitions, the
+    6-partition instantiations, the capsule-range split."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    mr.run_static_case(emu, 10, code, k_mult, p_mult, C=C, E=E)
 
 
 @pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (12.6, 624), (24.2, 0)])
@@ -34,5 +43,5 @@ def test_emu_split_layout_transforms(emu, monkeypatch):
     change of the difference signal, the combine of the two half-size inverses; static (two k-tiles, ragged partitions)
     and moving events, every row against the oracle."""
     monkeypatch.setenv("AL_SPLIT", "1")
-    mr.run_static_case(emu, 11, 1121202, 10.0006, 5.002, C=2, E=1, expect_split=True)
+    mr.run_static_case(emu, 11, 3120601, 10.0006, 5.002, C=2, E=1, expect_split=True)
     mr.run_moving_case(emu, 11, 4.3, n_irs=10, k_mult=14.2, expect_moving=612, C=1, E=1)

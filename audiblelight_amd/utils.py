@@ -94,3 +94,4 @@ def as_lazy(mapping) -> LazyAudioDict:
         for k, v in dict(mapping).items():
             OrderedDict.__setitem__(out, k, v)
     return out
+

@@ -78,6 +78,7 @@ SYMBOLS = {
     "al_emitter_gains": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_emitter_norm_sums": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_emitter_gains_from_sums": (ct.c_int, [ct.POINTER(AlBatch), ct.c_int32, _S]),
+    "al_forward_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_signal_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),

@@ -107,12 +107,14 @@ class BatchDriver:
             prev.synchronize()   # the slot's pinned clip buffer may still be the source of an H2D copy in flight
         audio_host = self._pinned_buffer("audio", torch.float32, pl.audio_floats, slot)
         r.pack_audio(pl, job.clips, out=audio_host.numpy())
+        device_clips = [(int(off), engine.as_clip_source(clip)) for off, clip in zip(pl.audio_offsets, job.clips)
+                        if engine.as_clip_source(clip).host is None]
+        if device_clips:   # clips already in HBM were produced by FX kernels on the compute stream: order the copies behind them
+            self.copy_stream.wait_stream(torch.cuda.current_stream(r.mem.device))
         with torch.cuda.stream(self.copy_stream):
             audio_dev = audio_host.to(r.mem.device, non_blocking=True)
-            for off, clip in zip(pl.audio_offsets, job.clips):   # clips already in HBM (device FX chain)
-                src = engine.as_clip_source(clip)
-                if src.host is None:
-                    audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]
+            for off, src in device_clips:
+                audio_dev[off: off + len(src)] = src.device[: len(src)]
             release = [] if self.async_h2d else None
             irs_dev, strides = r.upload_irs(job.irs, async_release=release)   # straight from the caller's memory
             ready = torch.cuda.Event()
@@ -330,7 +332,8 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
                 scene = scene()
             os.makedirs(folder, exist_ok=True)
             per_mic = scene_jobs(scene, name, driver.r)
-            meta[name] = (scene, [j.name for j in per_mic])
+            # only the (small) metadata dictionary outlives the scene: a dataset run must not keep every clip alive
+            meta[name] = (scene.to_dict() if hasattr(scene, "to_dict") else {}, [j.name for j in per_mic])
             yield from per_mic
 
     def path_of(job):
@@ -340,8 +343,7 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     rep = driver.run(jobs(), output_dir=output_dir, subtype=subtype, path_of=path_of)
     rep.skipped.extend(skipped)
     if metadata_json:
-        for name, (scene, job_names) in meta.items():
-            d = scene.to_dict() if hasattr(scene, "to_dict") else {}
+        for name, (d, job_names) in meta.items():
             d["time"] = max(rep.latencies.get(j, 0.0) for j in job_names)
             with open(os.path.join(output_dir, name, f"{metadata_fname}.json"), "w") as fh:
                 json.dump(d, fh, indent=4, ensure_ascii=False)

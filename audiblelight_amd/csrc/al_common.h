@@ -138,6 +138,7 @@ __device__ __forceinline__ void block_reduce3(float &a_sum, float &b_max, float 
 // launchers of the transform kernels (defined in al_transforms.hip); return hipGetLastError() of the launch
 hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream);
+hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream);
 hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream);
 

@@ -900,6 +900,11 @@ int al_emitter_gains_from_sums(const al_batch *b, int32_t total_capsules, al_str
   return check_launch("k_emitter_gains(from sums)");
 }
 
+int al_forward_spectra(const al_batch *b, al_stream_t stream) {
+  if (int rc = check_batch(b)) return rc;
+  return check_error(al::launch_forward_spectra(b, (hipStream_t)stream), "k_forward_spectra");
+}
+
 int al_signal_spectra(const al_batch *b, al_stream_t stream) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_streams <= 0 || b->max_nj <= 0) return AL_OK;
@@ -1073,9 +1078,8 @@ int al_event_levels_from_stats(const al_batch *b, int32_t total_capsules, al_str
 
 int al_render_batch(const al_batch *b, al_stream_t stream) {
   int rc;
-  if ((rc = al_ir_spectra(b, stream))) return rc;
+  if ((rc = al_forward_spectra(b, stream))) return rc;
   if ((rc = al_emitter_gains(b, stream))) return rc;
-  if ((rc = al_signal_spectra(b, stream))) return rc;
   if ((rc = al_spectral_mac(b, stream))) return rc;
   if ((rc = al_mac_synthesis(b, stream))) return rc;
   if ((rc = al_block_synthesis(b, stream))) return rc;

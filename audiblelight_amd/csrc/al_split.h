@@ -67,13 +67,11 @@ __device__ __forceinline__ void split_odd_input(const float2 (&d)[G::E], float2 
 
 // ------------------------------------------------------------------ 1s. IR partition spectra, split layout
 template <int LOG2M>
-__global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_ir_spectra_split(al_batch b) {
+__device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 *s, float *red, int p, int c, int nz) {
   using G = FftGeom<LOG2M - 1, 16>;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
-  __shared__ float2 s[G::LDS_ELEMS];
-  __shared__ float red[48];
   const int tid = threadIdx.x;
-  const int p = blockIdx.x, c = blockIdx.y, n = b.emitter0 + blockIdx.z;
+  const int n = b.emitter0 + nz;
   const float2 *table = reinterpret_cast<const float2 *>(b.twiddle);
   FftTwiddles<G> tw;
   load_fft_twiddles<G, -1, 2>(tw, table, tid);
@@ -100,37 +98,38 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
     energy = fmaf(a[i].y, a[i].y, energy);
   }
   const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;             // global (energy partials)
-  const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;   // chunk-local spectrum
+  const int64_t hblk = ((int64_t)nz * b.n_capsules + c) * b.n_partitions + p;           // chunk-local spectrum
   float2 *out = reinterpret_cast<float2 *>(b.hspec) + hblk * B;
-#ifndef AL_SPLIT_DEBUG
-#define AL_SPLIT_DEBUG 0
-#endif
-  if (AL_SPLIT_DEBUG != 1) {   // odd half first: the second half of the window is zero, so d = s = h and `a` stays for the even half
+  {   // odd half first: the second half of the window is zero, so d = s = h and `a` stays for the even half
     float2 u[E];
     split_odd_input<G>(a, u, s, w8, tid);
     fft_regs_to_regs<G, -1>(u, s, tw, tid);
 #pragma unroll
     for (int i = 0; i < E; ++i) stream_store<4>(out + M + tid + T * i, u[i]);
   }
-  if (AL_SPLIT_DEBUG != 2) {
-    fft_regs_to_regs<G, -1>(a, s, tw, tid);
-    real_unpack_store_regs<G>(a, s, tw.w0, tid, out);
-  }
+  fft_regs_to_regs<G, -1>(a, s, tw, tid);
+  real_unpack_store_regs<G>(a, s, tw.w0, tid, out);
   __syncthreads();   // `red` below shares nothing with the image, but the image's last reads must be over
   float mx = 0.f, zz = 0.f;
   block_reduce3(energy, mx, zz, red, tid, T);
   if (tid == 0) b.ir_energy[blk] = energy;
 }
 
+template <int LOG2M>
+__global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_ir_spectra_split(al_batch b) {
+  __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
+  __shared__ float red[48];
+  ir_spectra_split_body<LOG2M>(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
 // ------------------------------------------------------------------ 3s. signal block spectra, split layout
 template <int LOG2M>
-__global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_signal_spectra_split(al_batch b) {
+__device__ __forceinline__ void signal_spectra_split_body(const al_batch &b, float2 *s, int jblock, int stream_index) {
   using G = FftGeom<LOG2M - 1, 16>;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
-  __shared__ float2 s[G::LDS_ELEMS];
   const int tid = threadIdx.x;
-  const al_stream st = b.streams[b.stream0 + blockIdx.y];
-  if ((int)blockIdx.x >= st.n_j) return;
+  const al_stream st = b.streams[b.stream0 + stream_index];
+  if (jblock >= st.n_j) return;
   const al_event ev = b.events[st.event];
   const float2 *table = reinterpret_cast<const float2 *>(b.twiddle);
   FftTwiddles<G> tw;
@@ -140,7 +139,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
   const bool moving = st.w_off >= 0 && st.w_len > 0;
   const float *w = b.wtab + (moving ? st.w_off : 0);
   const float clip_gain = st.gain * (b.clip_scale ? b.clip_scale[st.event] : 1.f);
-  const int j = st.j_lo + blockIdx.x;
+  const int j = st.j_lo + jblock;
   const int t0 = (j - 1) * B;  // window [(j-1)B, (j+1)B)
   const int last = ev.len - 1;
   float2 h1[E], h2[E];
@@ -170,7 +169,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
   };
   load_half(h1, t0);
   load_half(h2, t0 + B);
-  float2 *out = reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + blockIdx.x) * B;
+  float2 *out = reinterpret_cast<float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 + jblock) * B;
 #pragma unroll
   for (int i = 0; i < E; ++i) {   // h1 <- s = w1 + w2, h2 <- d = w1 - w2
     const float2 p = h1[i], q = h2[i];
@@ -186,6 +185,27 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
   }
   fft_regs_to_regs<G, -1>(h1, s, tw, tid);
   real_unpack_store_regs<G>(h1, s, tw.w0, tid, out);
+}
+
+template <int LOG2M>
+__global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_signal_spectra_split(al_batch b) {
+  __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
+  signal_spectra_split_body<LOG2M>(b, s, blockIdx.x, blockIdx.y);
+}
+
+// Both forward transforms in ONE launch (they are independent): the 1 536 signal windows of a cfg2 scene are a 0.05 ms
+// kernel of their own otherwise, too short to fill the chip.  Workgroup ids [0, n_sig) are signal jobs, the rest IR jobs.
+template <int LOG2M>
+__global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_forward_spectra_split(al_batch b, int n_sig) {
+  __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
+  __shared__ float red[48];
+  const int id = blockIdx.x;
+  if (id < n_sig) {
+    signal_spectra_split_body<LOG2M>(b, s, id % b.max_nj, id / b.max_nj);
+  } else {
+    const int q = id - n_sig, pc = b.n_partitions * b.n_capsules;
+    ir_spectra_split_body<LOG2M>(b, s, red, q % b.n_partitions, (q / b.n_partitions) % b.n_capsules, q / pc);
+  }
 }
 
 // ------------------------------------------------------------------ 5s. block synthesis, split layout

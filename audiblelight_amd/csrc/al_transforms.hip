@@ -254,6 +254,24 @@ hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
   return hipGetLastError();
 }
 
+// IR + signal spectra in one launch where the split layout makes them the same shape of job; else two launches.
+hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream) {
+  const bool have_ir = b->n_emitters > 0, have_sig = b->n_streams > 0 && b->max_nj > 0;
+  if (use_split(b) && have_ir && have_sig) {
+    const int64_t n_sig = (int64_t)b->max_nj * b->n_streams;
+    const int64_t n_ir = (int64_t)b->n_partitions * b->n_capsules * b->n_emitters;
+    if (n_sig + n_ir <= 0x7fffffff) {
+      const dim3 grid((unsigned)(n_sig + n_ir));
+      AL_DISPATCH_SPLIT(b, k_forward_spectra_split, grid, *b, (int)n_sig);
+      return hipGetLastError();
+    }
+  }
+  if (have_ir)
+    if (hipError_t e = launch_ir_spectra(b, stream)) return e;
+  if (have_sig) return launch_signal_spectra(b, stream);
+  return hipSuccess;
+}
+
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream) {
   const dim3 grid(b->max_nj, b->n_streams);
   if (use_split(b)) {

@@ -344,8 +344,7 @@ class Renderer:
 class PreparedBatch:
     """One batch with every buffer resident in HBM; ``run()`` only enqueues kernels."""
 
-    STAGES = ("al_ir_spectra", "al_emitter_gains", "al_signal_spectra", "al_spectral_mac", "al_block_synthesis",
-              "al_event_levels")
+    STAGES = ("al_forward_spectra", "al_emitter_gains", "al_spectral_mac", "al_block_synthesis", "al_event_levels")
 
     def __init__(self, renderer: Renderer, plan: BatchPlan, bufs: dict, descs: List[_hip.AlBatch], lanes: int = 1):
         self.renderer, self.plan, self.bufs, self.descs, self.lanes = renderer, plan, bufs, descs, lanes
@@ -385,7 +384,7 @@ class PreparedBatch:
             return self.STAGES
         ev = self.plan.events[desc.event0: desc.event0 + desc.n_events]
         moving, tiled = bool((ev["n_streams"] > 1).any()), bool((ev["n_streams"] == 0).any())
-        out = ["al_ir_spectra", "al_emitter_gains", "al_signal_spectra"]
+        out = ["al_forward_spectra", "al_emitter_gains"]
         if moving:
             out.append("al_spectral_mac")
         if bool((ev["n_streams"] == 1).any()):

@@ -172,6 +172,8 @@ int al_twiddle_init(float *twiddle, int log2_block, al_stream_t stream);
 int al_ir_spectra(const al_batch *b, al_stream_t stream);      /* A1 energy partials + IR partition spectra */
 int al_emitter_gains(const al_batch *b, al_stream_t stream);   /* A1 normalize_irs scalar per emitter */
 int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 envelope + block spectra */
+int al_forward_spectra(const al_batch *b, al_stream_t stream); /* al_ir_spectra + al_signal_spectra (independent of each other):
+                                                                  one launch in the split layout, else the two in turn */
 int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
 /* Which kernel instantiations al_spectral_mac launches for this batch (no launch; used by the parity tests to assert
  * the regime they cover).  *static_code = the kernel that takes one-emitter events: 1000000*KSPLIT + 10000*KT + 100*PT + VB

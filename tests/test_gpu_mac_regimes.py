@@ -79,9 +79,8 @@ def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
         col += n_emit
     pl = planning.plan_batch(specs, C, L, sr, log2_block=13)
     batch = gpu.prepare(pl, clips, np.concatenate(irs, axis=1))
-    assert mr.is_fused(batch) and list(batch.stage_names()) == ["al_ir_spectra", "al_emitter_gains", "al_signal_spectra",
-                                                                "al_spectral_mac", "al_mac_synthesis", "al_block_synthesis",
-                                                                "al_event_levels"]
+    assert mr.is_fused(batch) and list(batch.stage_names()) == ["al_forward_spectra", "al_emitter_gains", "al_spectral_mac",
+                                                                "al_mac_synthesis", "al_block_synthesis", "al_event_levels"]
     res = batch.run()
     res.check_finite()
     for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):

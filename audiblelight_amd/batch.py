@@ -4,12 +4,13 @@ The reference's dataset scripts render scenes in a serial loop (scripts/generate
 scripts/seld/generate_dataset.py:96-260) and write one WAV per microphone (core.py:1840-1847).  Here the
 stages of consecutive scenes overlap:
 
-    scene i+1:  host planning + pinned staging + H2D copy      (copy stream)
-    scene i  :  render + mixdown                                (compute stream)
-    scene i-1:  D2H of scene.audio + WAV encode                 (download stream + writer thread)
+    scene i+2:  host planning, clips packed into page-locked memory   (planner thread)
+    scene i+1:  H2D copy of clips and IRs                              (uploader thread, copy stream; PCIe-bound)
+    scene i  :  render + mixdown + frame encoding into host memory     (calling thread, compute stream)
+    scene i-1:  WAV files / callbacks                                  (writer threads)
 
-Only plumbing lives here (torch streams/events, pinned buffers, a thread for file I/O); all arithmetic is
-in the kernels behind the C ABI.
+Only plumbing lives here (torch streams/events, pinned buffers, threads for staging and file I/O); all arithmetic
+is in the kernels behind the C ABI.
 """
 from __future__ import annotations
 
@@ -50,7 +51,7 @@ class BatchReport:
     files: List[str] = field(default_factory=list)
     skipped: List[str] = field(default_factory=list)     # scenes left alone because their output exists
     latencies: dict = field(default_factory=dict)        # scene name -> seconds from staging to written / delivered
-    host_s: dict = field(default_factory=dict)           # producer-thread seconds by stage: stage / enqueue / wait_writer
+    host_s: dict = field(default_factory=dict)           # seconds by stage: plan / upload (feeder threads), wait_upload / enqueue / wait_writer (caller)
 
     @property
     def scene_seconds_per_second(self) -> float:
@@ -70,7 +71,8 @@ class BatchDriver:
     device, the download stream copies that into page-locked memory and a writer thread puts it on disk.
     """
 
-    def __init__(self, renderer: Optional[engine.Renderer] = None, depth: int = 2, subtype: str = "PCM_16"):
+    def __init__(self, renderer: Optional[engine.Renderer] = None, depth: int = 2, subtype: str = "PCM_16",
+                 writers: int = 4):
         self.r = renderer or engine.Renderer()
         if not hasattr(self.r.mem, "torch"):
             raise RuntimeError("BatchDriver needs the torch/ROCm memory provider")
@@ -78,13 +80,18 @@ class BatchDriver:
             raise ValueError(f"subtype must be one of {sorted(SUBTYPES)}")
         self.torch = self.r.mem.torch
         self.depth = max(1, depth)
-        self.subtype = subtype
+        self.writers = max(1, writers)   # threads putting finished scenes on disk (one WAV of a 60 s / 32-capsule scene
+        self.subtype = subtype           # takes longer to write than the scene takes to upload, render and download)
         dev = self.r.mem.device
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
         self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
         self._slot_ready = {}   # slot -> H2D event of the scene that last used the slot's pinned clip buffer
         # default: the runtime's pageable copy (holds this thread); AL_H2D=async: page-lock in place + asynchronous DMA
+        # AL_D2H=kernel: the encode / copy kernels store straight into page-locked host memory instead of a DMA on the
+        # download stream; slower once uploads run from their own thread (the stores slow the concurrent H2D: 17.4 vs
+        # 15.5 ms per cfg2 scene, profiles/r02_e2e_probe.txt)
+        self.zero_copy_d2h = os.environ.get("AL_D2H", "dma") == "kernel"
         self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
@@ -94,8 +101,8 @@ class BatchDriver:
             pool.append(self.torch.empty(int(numel), dtype=dtype).pin_memory())
         return pool[slot]
 
-    # -- stage 1: host planning + upload on the copy stream
-    def _stage(self, job: SceneJob, slot: int = 0):
+    # -- stage 1a: host planning + clip packing into page-locked memory (CPU only)
+    def _plan(self, job: SceneJob, slot: int = 0):
         torch, r = self.torch, self.r
         c, n, l = job.irs.shape
         pl = planning.plan_batch(job.specs, c, l, job.sample_rate)
@@ -107,10 +114,19 @@ class BatchDriver:
             prev.synchronize()   # the slot's pinned clip buffer may still be the source of an H2D copy in flight
         audio_host = self._pinned_buffer("audio", torch.float32, pl.audio_floats, slot)
         r.pack_audio(pl, job.clips, out=audio_host.numpy())
+        return dict(job=job, plan=pl, mix=mix_plan, audio_host=audio_host, slot=slot, t0=time.perf_counter(),
+                    h2d=job.irs.nbytes + pl.audio_floats * 4)
+
+    # -- stage 1b: H2D on the copy stream (PCIe-bound; the pageable IR copy holds the calling thread, not the GIL)
+    def _upload(self, st, compute_stream=None):
+        torch, r = self.torch, self.r
+        job, pl, audio_host = st["job"], st["plan"], st["audio_host"]
+        if compute_stream is None:
+            compute_stream = torch.cuda.current_stream(r.mem.device)
         device_clips = [(int(off), engine.as_clip_source(clip)) for off, clip in zip(pl.audio_offsets, job.clips)
                         if engine.as_clip_source(clip).host is None]
         if device_clips:   # clips already in HBM were produced by FX kernels on the compute stream: order the copies behind them
-            self.copy_stream.wait_stream(torch.cuda.current_stream(r.mem.device))
+            self.copy_stream.wait_stream(compute_stream)
         with torch.cuda.stream(self.copy_stream):
             audio_dev = audio_host.to(r.mem.device, non_blocking=True)
             for off, src in device_clips:
@@ -119,10 +135,12 @@ class BatchDriver:
             irs_dev, strides = r.upload_irs(job.irs, async_release=release)   # straight from the caller's memory
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
-        self._slot_ready[slot] = ready
-        h2d = job.irs.nbytes + pl.audio_floats * 4
-        return dict(job=job, plan=pl, mix=mix_plan, irs=irs_dev, strides=strides, audio=audio_dev, ready=ready,
-                    h2d=h2d, slot=slot, t0=time.perf_counter(), release=release or [])
+        self._slot_ready[st["slot"]] = ready
+        st.update(irs=irs_dev, strides=strides, audio=audio_dev, ready=ready, release=release or [])
+        return st
+
+    def _stage(self, job: SceneJob, slot: int = 0):
+        return self._upload(self._plan(job, slot))
 
     # -- stage 2: kernels on the current (compute) stream
     def _render(self, st):
@@ -150,23 +168,39 @@ class BatchDriver:
         cur = torch.cuda.current_stream(r.mem.device)
         fmt, np_dtype = SUBTYPES[subtype]
         frames_dev = None
-        if want_frames:
+        if want_frames and not self.zero_copy_d2h:
             tdt = torch.int16 if np_dtype == np.int16 else torch.float32
             frames_dev = torch.empty(c * t, dtype=tdt, device=r.mem.device)
             r.lib.call("al_encode_frames", st["scene"].data_ptr(), c, t, fmt, frames_dev.data_ptr(),
                        ct.c_void_p(cur.cuda_stream))
+        if self.zero_copy_d2h:
+            # The kernels write straight into page-locked HOST memory (it is mapped into the GPU's address space): the
+            # "download" is then PCIe stores issued by the CUs (16 bytes per lane).
+            if want_frames:
+                tdt = torch.int16 if np_dtype == np.int16 else torch.float32
+                host = self._pinned_buffer("frames", tdt, c * t, st.get("out_slot", st["slot"]))
+                r.lib.call("al_encode_frames", st["scene"].data_ptr(), c, t, fmt, host.data_ptr(), ct.c_void_p(cur.cuda_stream))
+                st["frames"] = host
+            if want_scene:
+                host = self._pinned_buffer("scene", torch.float32, c * t, st.get("out_slot", st["slot"]))
+                r.lib.call("al_wrap_copy", st["scene"].data_ptr(), c * t, host.data_ptr(), c * t, ct.c_void_p(cur.cuda_stream))
+                st["host"] = host
+            landed = torch.cuda.Event()
+            landed.record(cur)
+            st.update(landed=landed)
+            return st
         done = torch.cuda.Event()
         done.record(cur)
         with torch.cuda.stream(self.down_stream):
             self.down_stream.wait_event(done)
             if want_frames:
                 frames_dev.record_stream(self.down_stream)
-                host = self._pinned_buffer("frames", frames_dev.dtype, c * t, st["slot"])
+                host = self._pinned_buffer("frames", frames_dev.dtype, c * t, st.get("out_slot", st["slot"]))
                 host.copy_(frames_dev, non_blocking=True)
                 st["frames"] = host
             if want_scene:
                 st["scene"].record_stream(self.down_stream)
-                host = self._pinned_buffer("scene", torch.float32, c * t, st["slot"])
+                host = self._pinned_buffer("scene", torch.float32, c * t, st.get("out_slot", st["slot"]))
                 host.copy_(st["scene"][: c * t], non_blocking=True)
                 st["host"] = host
             landed = torch.cuda.Event()
@@ -191,6 +225,8 @@ class BatchDriver:
         rep = BatchReport()
         sink: "queue.Queue" = queue.Queue(maxsize=self.depth + 1)
         failure: List[BaseException] = []
+        book, callback_lock = threading.Lock(), threading.Lock()
+        written: List[tuple] = []
         want_frames, want_scene = output_dir is not None, on_scene is not None
         if path_of is None:
             path_of = lambda job: os.path.join(output_dir, f"{job.name}.wav")  # noqa: E731
@@ -208,13 +244,17 @@ class BatchDriver:
                 path = path_of(st["job"])
                 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
                 wavfile.write(path, int(st["job"].sample_rate), st["frames"].numpy().reshape(t, c))
-                rep.files.append(path)
-                rep.d2h_bytes += st["frames"].numel() * st["frames"].element_size()
+                with book:
+                    written.append((st["index"], path))
+                    rep.d2h_bytes += st["frames"].numel() * st["frames"].element_size()
             if want_scene:
                 view = st["host"].numpy().reshape(c, t)
-                on_scene(st["job"].name, view.copy() if copy_for_callback else view)
-                rep.d2h_bytes += c * t * 4
-            rep.latencies[st["job"].name] = time.perf_counter() - st["t0"]
+                with callback_lock:   # callbacks never run concurrently, whatever the number of writer threads
+                    on_scene(st["job"].name, view.copy() if copy_for_callback else view)
+                with book:
+                    rep.d2h_bytes += c * t * 4
+            with book:
+                rep.latencies[st["job"].name] = time.perf_counter() - st["t0"]
 
         def writer():
             while True:
@@ -230,46 +270,114 @@ class BatchDriver:
 
         if output_dir is not None:
             os.makedirs(output_dir, exist_ok=True)
-        th = threading.Thread(target=writer, daemon=True)
-        th.start()
+        threads = [threading.Thread(target=writer, daemon=True) for _ in range(self.writers if want_frames else 1)]
+        for th in threads:
+            th.start()
         t0 = time.perf_counter()
-        n_slots = self.depth + 3   # live at once: being written, `depth` queued, being rendered, being staged
-        index = 0
+        # page-locked output buffers live at once: being rendered, `depth` + 1 queued for the writers, one per writer thread
+        # (back-pressure of the bounded queue guarantees it); clip staging buffers are guarded by their H2D event
+        out_slots, in_slots = self.depth + 2 + len(threads), 4
+        compute = self.torch.cuda.current_stream(self.r.mem.device)
+        planned: "queue.Queue" = queue.Queue(maxsize=1)
+        uploaded: "queue.Queue" = queue.Queue(maxsize=1)
+        stop = threading.Event()
+        clock = {}
 
-        def next_job(it):
-            for job in it:
-                if skip_existing and want_frames and os.path.exists(path_of(job)):
-                    rep.skipped.append(job.name)
-                    continue
-                return job
+        def spend(key, dt):
+            with book:
+                clock[key] = clock.get(key, 0.0) + dt
+
+        def hand_over(q, item):
+            while not stop.is_set():
+                try:
+                    q.put(item, timeout=0.05)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def planner():          # the jobs iterable is consumed HERE: scene factories overlap with upload and render too
+            try:
+                index = 0
+                for job in jobs:
+                    if stop.is_set():
+                        break
+                    if skip_existing and want_frames and os.path.exists(path_of(job)):
+                        rep.skipped.append(job.name)
+                        continue
+                    ta = time.perf_counter()
+                    st = self._plan(job, index % in_slots)
+                    st.update(index=index, out_slot=index % out_slots)
+                    index += 1
+                    spend("plan", time.perf_counter() - ta)
+                    if not hand_over(planned, st):
+                        break
+            except BaseException as exc:  # noqa: BLE001  (re-raised by run())
+                failure.append(exc)
+            finally:
+                hand_over(planned, None)
+
+        def take(q):
+            while not stop.is_set():
+                try:
+                    return q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
             return None
 
+        def uploader():
+            try:
+                while True:
+                    st = take(planned)
+                    if st is None:
+                        break
+                    ta = time.perf_counter()
+                    self._upload(st, compute)
+                    spend("upload", time.perf_counter() - ta)
+                    if not hand_over(uploaded, st):
+                        break
+            except BaseException as exc:  # noqa: BLE001
+                failure.append(exc)
+                stop.set()
+            finally:
+                hand_over(uploaded, None)
+
+        feeders = [threading.Thread(target=planner, daemon=True), threading.Thread(target=uploader, daemon=True)]
+        for th in feeders:
+            th.start()
         try:
-            it = iter(jobs)
-            nxt = next_job(it)
-            staged = self._stage(nxt, index % n_slots) if nxt is not None else None
-            while staged is not None and not failure:
-                cur = staged
+            while not failure:
                 ta = time.perf_counter()
-                st = self._download(self._render(cur), want_frames, want_scene, subtype)   # enqueue only (asynchronous)
+                cur = take(uploaded)
+                if cur is None:
+                    break
                 tb = time.perf_counter()
-                nxt = next_job(it)
-                index += 1
-                # the upload of scene i+1 (host-blocking, PCIe-bound) runs while the GPU renders scene i
-                staged = self._stage(nxt, index % n_slots) if nxt is not None else None
+                st = self._download(self._render(cur), want_frames, want_scene, subtype)   # enqueue only (asynchronous)
                 tc = time.perf_counter()
                 rep.n_scenes += 1
                 rep.scene_seconds += cur["job"].duration
                 rep.h2d_bytes += cur["h2d"]
-                sink.put(st)          # blocks while the writer is `depth` + 1 scenes behind: back-pressure
+                sink.put(st)          # blocks while the writers are `depth` + 1 scenes behind: back-pressure
                 td = time.perf_counter()
-                for key, dt in (("enqueue", tb - ta), ("stage", tc - tb), ("wait_writer", td - tc)):
-                    rep.host_s[key] = rep.host_s.get(key, 0.0) + dt
+                for key, dt in (("wait_upload", tb - ta), ("enqueue", tc - tb), ("wait_writer", td - tc)):
+                    spend(key, dt)
         finally:
-            sink.put(None)
-            th.join()
+            stop.set()                # on failure: the feeders stop waiting on their queues
+            while True:               # ... and whatever they had queued is dropped
+                try:
+                    uploaded.get_nowait()
+                except queue.Empty:
+                    break
+            for th in feeders:
+                th.join()
+            for _ in threads:
+                sink.put(None)
+            for th in threads:
+                th.join()
         self.torch.cuda.synchronize(self.r.mem.device)
         rep.wall_s = time.perf_counter() - t0
+        rep.host_s.update(clock)
+        rep.files.extend(path for _, path in sorted(written))   # job order, whichever writer thread finished first
         if failure:
             raise failure[0]
         return rep

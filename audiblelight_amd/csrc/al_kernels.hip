@@ -796,6 +796,33 @@ __global__ __launch_bounds__(256) void k_encode_frames(const float *__restrict__
     tile[r + ty][tx] = (c < n_capsules && t0 + tx < n_samples) ? scene[(int64_t)c * n_samples + t0 + tx] : 0.f;
   }
   __syncthreads();
+  // 16 bytes per store where the capsule count allows it (the destination may be page-locked HOST memory: every store
+  // is then a PCIe write, and 2- or 4-byte stores make 64 / 128-byte packets)
+  if (PCM16 && (n_capsules & 7) == 0) {
+    const int tl = threadIdx.x >> 2, cg = (threadIdx.x & 3) * 8;   // one frame's 8 consecutive capsules
+    const int64_t t = t0 + tl;
+    if (t < n_samples && c0 + cg < n_capsules) {
+      int16_t q[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) q[i] = (int16_t)fmin(fmax(rint((double)tile[cg + i][tl] * 32767.0), -32768.0), 32767.0);
+      struct alignas(16) Frames8 { uint32_t w[4]; } v;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v.w[i] = (uint32_t)(uint16_t)q[2 * i] | ((uint32_t)(uint16_t)q[2 * i + 1] << 16);
+      *reinterpret_cast<Frames8 *>(reinterpret_cast<int16_t *>(out) + t * n_capsules + c0 + cg) = v;
+    }
+    return;
+  }
+  if (!PCM16 && (n_capsules & 3) == 0) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int j = threadIdx.x + 256 * pass, tl = j >> 3, cg = (j & 7) * 4;   // one frame's 4 consecutive capsules
+      const int64_t t = t0 + tl;
+      if (t < n_samples && c0 + cg < n_capsules)
+        *reinterpret_cast<float4 *>(reinterpret_cast<float *>(out) + t * n_capsules + c0 + cg) =
+            make_float4(tile[cg][tl], tile[cg + 1][tl], tile[cg + 2][tl], tile[cg + 3][tl]);
+    }
+    return;
+  }
   const int cl = threadIdx.x & 31, tl = threadIdx.x >> 5;
 #pragma unroll
   for (int tt = 0; tt < 64; tt += 8) {
@@ -1388,6 +1415,7 @@ int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *ta
 int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream) {
   if (!scene || !out || n_capsules <= 0 || n_samples <= 0 || (format != AL_FRAMES_F32 && format != AL_FRAMES_PCM16))
     return fail(AL_E_BADARG, "bad encode_frames arguments");
+  if (((uintptr_t)out & 15) != 0) return fail(AL_E_BADARG, "encode_frames: output must be 16-byte aligned");
   const dim3 grid((unsigned)((n_samples + 63) / 64), (unsigned)((n_capsules + 31) / 32));
   if (format == AL_FRAMES_PCM16)
     hipLaunchKernelGGL((al::k_encode_frames<true>), grid, dim3(256), 0, (hipStream_t)stream, scene, n_capsules, n_samples, out);

@@ -228,7 +228,7 @@ def main():
     if args.gather is None:
         args.gather = world > 1
     if args.end_to_end is None:
-        args.end_to_end = 8 if world == 1 else 0
+        args.end_to_end = 16 if world == 1 else 0
     if args.dropin is None:
         args.dropin = 5 if world == 1 else 0
     emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements

@@ -51,3 +51,4 @@ def test_large_noise_lengths_statistics():
     small = amb.powerlaw_psd_gaussian(1, (2, 100_003), seed=3)      # 100003 is prime -> Bluestein
     ref = orc.powerlaw_noise(1, (2, 100_003), seed=3)
     assert np.sqrt(np.mean((small - ref) ** 2)) / ref.std() < 1e-5
+test_encode_frames_every_store_path = scenarios.test_encode_frames_every_store_path

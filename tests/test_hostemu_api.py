@@ -451,3 +451,29 @@ def test_ir_ingest_ragged_packing_and_resampling():
         m = min(n_out, ref.shape[-1])
         assert rel_rms(got[..., :m], ref[..., :m]) < 1e-5
     assert ingest.resample_irs(r, h, 48000, 48000) is not None
+
+
+def test_encode_frames_every_store_path():
+    """al_encode_frames: (C, T) float32 scene -> (T, C) interleaved WAV payload (core.py:1840-1847, soundfile's PCM_16
+    default = lrint(x * 0x7FFF), saturated).  Capsule counts that take the 16-byte store paths (C % 8 == 0 for PCM_16,
+    C % 4 == 0 for float) and ones that do not, lengths that end inside a 64-frame tile, values beyond full scale."""
+    import ctypes as ct
+
+    r = syn.get_renderer()
+    rng = np.random.default_rng(11)
+    for C, T in ((32, 1000), (8, 64), (40, 777), (4, 130), (12, 65), (5, 333), (1, 50)):
+        scene = (rng.standard_normal((C, T)) * 0.6).astype(np.float32)
+        scene[0, :4] = (1.5, -1.5, 1.0, -1.0)
+        dev = r.mem.upload(scene.reshape(-1))
+        for fmt, dtype in ((_hip.FRAMES_PCM16, np.int16), (_hip.FRAMES_F32, np.float32)):
+            out = r.mem.zeros(C * T + 8, dtype)
+            r.lib.call("al_encode_frames", r.mem.ptr(dev), C, T, fmt, r.mem.ptr(out), r.mem.stream())
+            r.mem.synchronize()
+            got = r.mem.download(out)
+            assert not got[C * T:].any(), (C, T, fmt)                    # nothing past the payload
+            got = got[: C * T].reshape(T, C)
+            if dtype == np.int16:
+                want = np.clip(np.rint(scene.T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+            else:
+                want = scene.T
+            np.testing.assert_array_equal(got, want, err_msg=str((C, T, fmt)))

@@ -282,6 +282,7 @@ class BatchDriver:
         uploaded: "queue.Queue" = queue.Queue(maxsize=1)
         stop = threading.Event()
         clock = {}
+        source_failure: List[BaseException] = []
 
         def spend(key, dt):
             with book:
@@ -312,8 +313,8 @@ class BatchDriver:
                     spend("plan", time.perf_counter() - ta)
                     if not hand_over(planned, st):
                         break
-            except BaseException as exc:  # noqa: BLE001  (re-raised by run())
-                failure.append(exc)
+            except BaseException as exc:  # noqa: BLE001  (re-raised by run() once the scenes already handed over are out)
+                source_failure.append(exc)
             finally:
                 hand_over(planned, None)
 
@@ -378,8 +379,8 @@ class BatchDriver:
         rep.wall_s = time.perf_counter() - t0
         rep.host_s.update(clock)
         rep.files.extend(path for _, path in sorted(written))   # job order, whichever writer thread finished first
-        if failure:
-            raise failure[0]
+        if failure or source_failure:
+            raise (failure or source_failure)[0]
         return rep
 
 

@@ -133,7 +133,7 @@ def test_batch_driver_writes_what_the_oracle_mixes(gpu, tmp_path):
     assert again.n_scenes == 0 and sorted(again.skipped) == [f"s{i}" for i in range(4)]
 
 
-def test_batch_driver_reports_writer_failures(gpu, tmp_path):
+def test_batch_driver_reports_writer_failures(gpu, tmp_path, monkeypatch):
     """A non-finite scene or a failing callback must surface from run() (the reference raises through
     librosa.util.valid_audio, synthesize.py:398,603), not die silently in the writer thread or hang the producer."""
     from audiblelight_amd import batch, synthetic
@@ -150,6 +150,27 @@ def test_batch_driver_reports_writer_failures(gpu, tmp_path):
 
     with pytest.raises(RuntimeError, match="callback failed"):
         batch.BatchDriver(gpu, depth=1).run(jobs[3:], on_scene=boom)
+
+    # failures in the feeder threads: the scene source raising half way (planner thread), IRs the uploader cannot take
+    def source():
+        yield from jobs[3:5]
+        raise KeyError("scene factory failed")
+
+    seen = []
+    with pytest.raises(KeyError, match="scene factory failed"):
+        batch.BatchDriver(gpu).run(source(), on_scene=lambda n, a: seen.append(n))
+    assert seen == ["s3", "s4"]                                  # what was handed over before the failure still came out
+    drv, real, calls = batch.BatchDriver(gpu), gpu.upload_irs, []
+
+    def flaky(irs, async_release=None):
+        calls.append(1)
+        if len(calls) == 2:
+            raise MemoryError("upload failed")
+        return real(irs, async_release=async_release)
+
+    monkeypatch.setattr(gpu, "upload_irs", flaky)
+    with pytest.raises(MemoryError, match="upload failed"):
+        drv.run(jobs[3:], on_scene=lambda n, a: None)
 
 
 def test_render_dataset_layout_and_audio(gpu, tmp_path):

@@ -29,17 +29,21 @@ class Event:
                  augmentations: Sequence = (), ref_ir_channel: Optional[int] = None,
                  direct_path_time_ms: Optional[Sequence[float]] = None, class_label: Optional[str] = None,
                  class_id: Optional[int] = None, filepath: Optional[str] = None, event_start: float = 0.0,
-                 duration: Optional[float] = None, metadata: Optional[dict] = None):
+                 duration: Optional[float] = None, metadata: Optional[dict] = None,
+                 native_sample_rate: Optional[int] = None):
         audio = np.asarray(audio)
         if audio.ndim != 1:
             raise ValueError("Event audio must be mono (1-D)")
         self.alias = alias
         self.sample_rate = int(sample_rate)
+        # ``audio`` is at ``native_sample_rate`` (default: the scene rate); resampling to ``sample_rate`` is the first
+        # step of the device chain (librosa.load(sr=...) does it on the host, event.py:520-527)
+        self.native_sample_rate = int(native_sample_rate) if native_sample_rate else self.sample_rate
         self._raw = np.ascontiguousarray(audio, dtype=np.float32)
         self.snr = float(snr)
         self.scene_start = float(scene_start)
         # the reference keeps the requested duration in seconds (event.py:131-133); the decoded clip may be a sample off
-        self.duration = float(duration) if duration is not None else len(self._raw) / self.sample_rate
+        self.duration = float(duration) if duration is not None else len(self._raw) / self.native_sample_rate
         self.scene_end = self.scene_start + self.duration
         self.n_emitters = int(n_emitters)
         self.is_moving = bool(self.n_emitters > 1 if is_moving is None else is_moving)
@@ -83,15 +87,30 @@ class Event:
         """Raw clip -> HBM once, the whole FX chain and the peak normalisation there (augmentation.run_chain)."""
         from . import augmentation, synthesize
 
+        from . import ingest
+
         device_fx = all(hasattr(a, "process_device") for a in self.augmentations)
+        clip = augmentation.DeviceClip(synthesize.get_renderer(), self._raw)
+        ingest.resample_clip(clip, self.native_sample_rate, self.sample_rate)
         if not device_fx:   # foreign callables (e.g. host pedalboard FX of the reference): run them where they live
-            out = self._raw.copy()
+            out = clip.host() if self.native_sample_rate != self.sample_rate else self._raw.copy()
             for aug in self.augmentations:
                 out = aug(out)
             clip = augmentation.DeviceClip(synthesize.get_renderer(), out)
             return augmentation.run_chain(clip, [], normalize)
-        clip = augmentation.DeviceClip(synthesize.get_renderer(), self._raw)
         return augmentation.run_chain(clip, self.augmentations, normalize)
+
+    @classmethod
+    def from_file(cls, filepath: str, alias: str, sample_rate: int, event_start: float = 0.0,
+                  duration: Optional[float] = None, **kwargs) -> "Event":
+        """An event from a WAV file, the way the reference's constructor + ``load_audio`` read one
+        (event.py:131-133,520-527): ``[event_start, event_start + duration)`` of the file, down-mixed to mono on the host,
+        resampled to ``sample_rate`` on the device when the chain first runs."""
+        from . import ingest
+
+        audio, native = ingest.read_wav_excerpt(filepath, event_start, duration)
+        return cls(alias, audio, sample_rate, filepath=filepath, event_start=event_start,
+                   duration=duration if duration is not None else len(audio) / native, native_sample_rate=native, **kwargs)
 
     def load_audio(self, ignore_cache: Optional[bool] = False, normalize: Optional[bool] = True) -> np.ndarray:
         """Clip after the FX chain and peak normalisation (event.py:496-539); cached in ``self.audio``.
@@ -114,7 +133,7 @@ class Event:
 
         if self.is_audio_loaded and not ignore_cache:
             return engine.ClipSource(host=np.ascontiguousarray(self.audio, dtype=np.float32), n=len(self.audio))
-        folded = augmentation.fold_scalars(self.augmentations)
+        folded = augmentation.fold_scalars(self.augmentations) if self.native_sample_rate == self.sample_rate else None
         if folded is not None:
             return engine.ClipSource(host=self._raw, n=len(self._raw), prescale=folded, normalize=True)
         clip = self._device_chain(True)

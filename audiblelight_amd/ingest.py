@@ -8,6 +8,10 @@
   parity with it is UNPINNED by definition; this implementation is pinned to
   ``scipy.signal.resample_poly(x, up, down)`` (default Kaiser-5 design), whose taps it uses.
 
+* ``resample_clip`` / ``read_wav_excerpt``: the source side (``librosa.load(path, sr, mono=True,
+  offset, duration)``, event.py:520-527): the excerpt is read from a WAV file on the host (decoding is host work in the
+  reference too), down-mixed, and resampled to the scene rate ON THE DEVICE as the first step of the event's FX chain.
+
 Host code here is index arithmetic and filter DESIGN (a few thousand taps); samples are touched by kernels only.
 """
 from __future__ import annotations
@@ -78,3 +82,53 @@ def resample_irs(renderer, irs: np.ndarray, orig_sr: int, target_sr: int) -> np.
         lib.call("al_resample_poly", mem.ptr(x) + 4 * r0 * n_in, nr, n_in, mem.ptr(h), half, up, down,
                  mem.ptr(out) + 4 * r0 * n_out, min(n_poly, n_out), n_out, mem.stream())
     return mem.download(out)[: rows * n_out].reshape(lead + (n_out,))
+
+
+def resampled_length(n_in: int, orig_sr: int, target_sr: int) -> int:
+    """``ceil(n * target_sr / orig_sr)``: the length librosa.resample(fix=True) returns (what librosa.load hands the
+    reference, event.py:520-527)."""
+    return int(np.ceil(n_in * (float(target_sr) / float(orig_sr))))
+
+
+def resample_clip(clip, orig_sr: int, target_sr: int) -> None:
+    """Resample an ``augmentation.DeviceClip`` in place (ping-pong buffer) from ``orig_sr`` to ``target_sr``: polyphase
+    FIR pinned to scipy.signal.resample_poly, output length ``ceil(n * ratio)`` (samples past resample_poly's own length
+    are zero, as librosa's fix_length pads)."""
+    if int(orig_sr) == int(target_sr):
+        return
+    ratio = Fraction(int(target_sr), int(orig_sr))
+    up, down = ratio.numerator, ratio.denominator
+    n_in = clip.n
+    n_poly = -(-n_in * up // down)
+    n_out = resampled_length(n_in, orig_sr, target_sr)
+    taps, half = resample_taps(up, down)
+    mem, lib = clip.r.mem, clip.r.lib
+    h = mem.upload(taps)
+    dst = clip.other(n_out)
+    lib.call("al_resample_poly", mem.ptr(clip.buf), 1, n_in, mem.ptr(h), half, up, down, mem.ptr(dst), min(n_poly, n_out), n_out,
+             mem.stream())
+    clip.swap(n_out)
+
+
+def read_wav_excerpt(path: str, offset: float = 0.0, duration: float = None) -> Tuple[np.ndarray, int]:
+    """``[offset, offset + duration)`` seconds of a RIFF/WAVE file as mono float32 at the FILE's sample rate (PCM 8/16/24/32
+    or float; other containers are the host decoder's business and raise).  Integer PCM is scaled like libsndfile
+    (``x / 2**(bits-1)``), channels are averaged like ``librosa.to_mono``; frames are cut the way ``librosa.load`` cuts
+    them (``int(offset * sr)`` frames in, ``int(duration * sr)`` frames long)."""
+    from scipy.io import wavfile
+
+    sr, data = wavfile.read(path, mmap=True)
+    start = int(offset * sr)
+    stop = data.shape[0] if duration is None else min(data.shape[0], start + int(duration * sr))
+    part = np.asarray(data[start:stop])
+    if part.dtype == np.uint8:
+        part = (part.astype(np.float32) - 128.0) / 128.0
+    elif part.dtype.kind == "i":
+        part = part.astype(np.float32) / float(2 ** (8 * part.dtype.itemsize - 1))   # 24-bit arrives left-justified in int32
+    elif part.dtype.kind == "f":
+        part = part.astype(np.float32)
+    else:
+        raise ValueError(f"unsupported WAV sample type {part.dtype}")
+    if part.ndim == 2:
+        part = part.mean(axis=1, dtype=np.float32)
+    return np.ascontiguousarray(part, dtype=np.float32), int(sr)

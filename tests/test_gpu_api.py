@@ -52,3 +52,4 @@ def test_large_noise_lengths_statistics():
     ref = orc.powerlaw_noise(1, (2, 100_003), seed=3)
     assert np.sqrt(np.mean((small - ref) ** 2)) / ref.std() < 1e-5
 test_encode_frames_every_store_path = scenarios.test_encode_frames_every_store_path
+test_event_from_wav_file_resamples_on_the_device = scenarios.test_event_from_wav_file_resamples_on_the_device

@@ -477,3 +477,48 @@ def test_encode_frames_every_store_path():
             else:
                 want = scene.T
             np.testing.assert_array_equal(got, want, err_msg=str((C, T, fmt)))
+
+
+def test_event_from_wav_file_resamples_on_the_device(tmp_path):
+    """an event read the way the reference reads one (librosa.load(path, sr, mono=True, offset,
+    duration), event.py:520-527): excerpt of a stereo 44.1 kHz PCM_16 file, mono down-mix, resampled to the scene rate on
+    the device as the first step of the FX chain (pinned to scipy.signal.resample_poly; librosa's soxr resampler is an
+    absent third-party algorithm), then FX + peak normalisation, one upload and no host round trip before the render."""
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+
+    from audiblelight_amd import ingest
+
+    rng = np.random.default_rng(21)
+    sr_file, sr = 44100, 48000
+    t = np.arange(int(1.5 * sr_file)) / sr_file
+    stereo = np.stack([0.5 * np.sin(2 * np.pi * 440 * t) + 0.05 * rng.standard_normal(len(t)),
+                       0.3 * np.sin(2 * np.pi * 1000 * t)], axis=1)
+    pcm = np.clip(np.rint(stereo * 32767), -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "clip.wav")
+    wavfile.write(path, sr_file, pcm)
+    offset, duration = 0.25, 0.8
+    ev = core.Event.from_file(path, "event000", sr, event_start=offset, duration=duration, snr=12.0,
+                              augmentations=[aug.Gain(gain_db=-3.0), aug.Invert()])
+    assert ev.native_sample_rate == sr_file and ev.duration == duration and ev.filepath == path
+    # the reference's steps on the host
+    mono = (pcm[int(offset * sr_file): int(offset * sr_file) + int(duration * sr_file)].astype(np.float32) / 32768.0).mean(axis=1)
+    np.testing.assert_allclose(ingest.read_wav_excerpt(path, offset, duration)[0], mono, atol=1e-7)
+    n_out = int(np.ceil(len(mono) * sr / sr_file))
+    res = resample_poly(mono.astype(np.float64), 160, 147)
+    want = np.zeros(n_out)
+    want[: min(n_out, len(res))] = res[:n_out]
+    want = -want * 10 ** (-3.0 / 20)
+    want = want / np.max(np.abs(want))
+    got = ev.load_audio()
+    assert got.shape == (n_out,) and got.dtype == np.float32
+    assert rel_rms(got, want) < 1e-5
+    assert ev._last_chain.uploads == 1 and ev._last_chain.downloads == 1
+    # ... and handed to the renderer without coming back: the scalar chain is NOT folded (the raw clip is at another rate)
+    ev.clear_audio()
+    src = ev.clip_source()
+    assert src.host is None and src.n == n_out
+    # a file already at the scene rate goes the folded way (raw clip + one device scalar)
+    wavfile.write(path, sr, pcm)
+    ev2 = core.Event.from_file(path, "event001", sr, augmentations=[aug.Gain(gain_db=-3.0)])
+    assert ev2.clip_source().host is not None and ev2.duration == pytest.approx(len(pcm) / sr)

@@ -216,7 +216,7 @@ class BatchDriver:
         ``path_of(job)``): (T, C) interleaved frames like ``soundfile.write(audio.T, sr)`` (core.py:1840-1847), subtype
         ``PCM_16`` (soundfile's default for WAV) or ``FLOAT``; ``skip_existing`` leaves scenes whose file exists alone
         (scripts/generate/benchmark.py:54-55).  ``on_scene(name, array)`` receives a (C, T) float32 array of its own
-        (a copy: the page-locked download buffers are reused ``depth + 3`` scenes later; ``copy_for_callback=False``
+        (a copy: the page-locked download buffers are reused a few scenes later (``depth + 2`` + writer threads); ``copy_for_callback=False``
         hands out the view instead, for callbacks that consume it before returning).  A failure in the writer thread
         (non-finite audio, disk error, callback error) stops the run and is re-raised here."""
         subtype = subtype or self.subtype

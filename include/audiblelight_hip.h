@@ -141,8 +141,8 @@ typedef struct {
 typedef struct {
   int32_t n_capsules;     /* rows of the scene buffer */
   int32_t n_samples;      /* round(scene.duration * sample_rate) (synthesize.py:331) */
-  int32_t tile;           /* samples per time tile */
-  int32_t n_tiles;
+  int32_t tile;           /* samples per time tile: 4096 */
+  int32_t n_tiles;        /* ceil(n_samples / tile) */
   int32_t accumulate;     /* 0: scene is overwritten, 1: scene already holds ambience (synthesize.py:335-356) */
   int32_t reserved;
   const int32_t *tile_ptr;  /* n_tiles + 1 */

@@ -154,3 +154,30 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
     bad = subprocess.run(cmd, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr
+
+
+def test_header_is_plain_c_and_the_c_host_links():
+    """include/audiblelight_hip.h must be usable from C (the boundary is a C ABI, not a C++ one): the plain-C host of
+    tests/c_caller compiles with gcc -std=c11 against it and links every entry point it calls (no GPU needed to link);
+    the struct sizes gcc sees are the ones the ctypes mirror uses."""
+    import ctypes as ct
+    import subprocess
+    import tempfile
+
+    import __graft_entry__
+    from audiblelight_amd import _hip
+
+    exe = __graft_entry__.build_c_caller()
+    assert os.path.exists(exe)
+    probe = r'''
+#include <stdio.h>
+#include "audiblelight_hip.h"
+int main(void) { printf("%zu %zu %zu %zu\n", sizeof(al_event), sizeof(al_stream), sizeof(al_batch), sizeof(al_mix)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as tmp:
+        src, out = os.path.join(tmp, "sizes.c"), os.path.join(tmp, "sizes")
+        with open(src, "w") as f:
+            f.write(probe)
+        subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", out])
+        sizes = [int(x) for x in subprocess.check_output([out], text=True).split()]
+    assert sizes == [_hip.EVENT_DTYPE.itemsize, _hip.STREAM_DTYPE.itemsize, ct.sizeof(_hip.AlBatch), ct.sizeof(_hip.AlMix)]

@@ -108,8 +108,8 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
                 extrapolated=n_events < len(scene.specs) or moving,
                 sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene"
                        + (f" with {n_irs_cap} of {scene.specs[0].n_emitters} IRs each" if moving else "")
-                       + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured, "
-                         f"scaled linearly in events x IRs")
+                       + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured"
+                       + (", scaled linearly in events x IRs" if n_events < len(scene.specs) or moving else ""))
 
 
 def load_pmc_traffic(config: str, log2_block: int):
@@ -200,7 +200,9 @@ def main():
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
-    ap.add_argument("--cpu-events", type=int, default=16, help="events timed for the CPU baseline (0 = skip)")
+    ap.add_argument("--cpu-events", type=int, default=None,
+                    help="events timed for the CPU baseline (0 = skip; default: the whole scene for cfg2 = 18 s on one core, "
+                         "a bounded sample for the larger configurations)")
     ap.add_argument("--cpu-workers", type=int, default=0, metavar="N",
                     help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64)")
     ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
@@ -227,6 +229,8 @@ def main():
                  f"(python bench.py --gpus N spawns them itself)")
     if args.gather is None:
         args.gather = world > 1
+    if args.cpu_events is None:
+        args.cpu_events = {"cfg2": 64, "cfg3": 1, "cfg4": 16, "cfg5": 4}.get(args.config, 64)
     if args.end_to_end is None:
         args.end_to_end = 16 if world == 1 else 0
     if args.dropin is None:

@@ -4,15 +4,21 @@ from audiblelight_amd import engine, plan as planning
 from oracle import synth_oracle as orc
 r = engine.Renderer()
 bad = 0
+checked = 0
 worst = 0.0
-for seed in range(400):
+for seed in range(int(os.environ.get("FUZZ_FROM", 0)), int(os.environ.get("FUZZ_TO", 400))):
     rng = np.random.default_rng(5000 + seed)
     log2_block = int(rng.integers(10, 15))
     m = seed % 3
     os.environ["AL_EXTRA_FLAGS"] = str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)) if m == 1 else ("4" if m == 2 else "0")
     os.environ["AL_FUSED"] = "1" if seed % 2 else "0"     # the experimental fused kernel takes the static events at B = 8192
     sr, C = 16000, int(rng.integers(1, 8))
-    L = int(rng.integers(1, 3 << log2_block))
+    if seed >= 400:   # long IRs (up to 14 partitions: both accumulate families) at small blocks, transform layout and accumulate kernel at random
+        log2_block = int(rng.integers(10, 13))
+        os.environ["AL_FUSED"] = "0"
+        os.environ["AL_SPLIT"] = str(int(rng.integers(0, 2)))
+        os.environ["AL_STATIC_MAC"] = str(int(rng.integers(0, 2)))
+    L = int(rng.integers(1, (14 if seed >= 400 else 3) << log2_block))
     specs, clips, irs, col = [], [], [], 0
     for _ in range(int(rng.integers(1, 5))):
         kind = rng.choice(["static", "static", "moving", "dry"])
@@ -34,10 +40,11 @@ for seed in range(400):
             den = np.sqrt(np.mean(want ** 2))
             err = np.sqrt(np.mean((got - want) ** 2)) / den if den > 0 else float(np.abs(got).max())
             worst = max(worst, err)
+            checked += 1
             if not err < 1e-4:
                 bad += 1
                 print("FAIL seed", seed, "event", i, "err", err, "lb", log2_block, "C", C, "L", L, len(a), sp.n_emitters, os.environ["AL_EXTRA_FLAGS"], flush=True)
     except Exception as ex:
         bad += 1
         print("EXC seed", seed, type(ex).__name__, str(ex)[:200], "lb", log2_block, "C", C, "L", L, [(len(c), s.n_emitters) for c, s in zip(clips, specs)], flush=True)
-print("done: failures", bad, "worst rel rms", worst)
+print("done: events checked", checked, "failures", bad, "worst rel rms", worst)

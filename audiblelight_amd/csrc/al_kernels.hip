@@ -286,10 +286,10 @@ __device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
   for (int c = c_begin; c < c_end; ++c) {
     if (NKTW > 1) __syncthreads();                              // both k-tiles start the capsule together
     if (!active) continue;
+    const int cn = min(c + 1, c_end - 1);                       // capsule whose spectra are requested during this one
     V acc[KT];
 #pragma unroll
     for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
-    const int cn = min(c + 1, c_end - 1);                       // capsule whose spectra are requested during this one
     for (int p0 = plo; p0 <= phi; p0 += PT) {
       if (!single) {
         load_window(p0);
@@ -1415,7 +1415,8 @@ int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *ta
 int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream) {
   if (!scene || !out || n_capsules <= 0 || n_samples <= 0 || (format != AL_FRAMES_F32 && format != AL_FRAMES_PCM16))
     return fail(AL_E_BADARG, "bad encode_frames arguments");
-  if (((uintptr_t)out & 15) != 0) return fail(AL_E_BADARG, "encode_frames: output must be 16-byte aligned");
+  const bool vector_stores = format == AL_FRAMES_PCM16 ? (n_capsules & 7) == 0 : (n_capsules & 3) == 0;
+  if (vector_stores && ((uintptr_t)out & 15) != 0) return fail(AL_E_BADARG, "encode_frames: output must be 16-byte aligned");
   const dim3 grid((unsigned)((n_samples + 63) / 64), (unsigned)((n_capsules + 31) / 32));
   if (format == AL_FRAMES_PCM16)
     hipLaunchKernelGGL((al::k_encode_frames<true>), grid, dim3(256), 0, (hipStream_t)stream, scene, n_capsules, n_samples, out);

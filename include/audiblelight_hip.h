@@ -297,7 +297,9 @@ int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *ta
 /* Output encoding for the WAV writer: (C, T) float32 scene -> (T, C) interleaved frames as
  * soundfile.write(mic_audio.T, sr) stores them (core.py:1840-1847).  AL_FRAMES_PCM16 is soundfile's default subtype for
  * WAV: int16 = lrint(x * 32767) (libsndfile's float->short normalisation), saturated; AL_FRAMES_F32 keeps float32.
- * Done on the device so the D2H copy is already the file payload (half the bytes for PCM_16). */
+ * Done on the device so the D2H copy is already the file payload (half the bytes for PCM_16).  `out` may be page-locked host
+ * memory; capsule counts that are multiples of 8 (PCM_16) / 4 (float32) are stored 16 bytes per lane and need a 16-byte
+ * aligned `out`. */
 #define AL_FRAMES_F32 0
 #define AL_FRAMES_PCM16 1
 int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream);

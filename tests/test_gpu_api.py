@@ -53,3 +53,4 @@ def test_large_noise_lengths_statistics():
     assert np.sqrt(np.mean((small - ref) ** 2)) / ref.std() < 1e-5
 test_encode_frames_every_store_path = scenarios.test_encode_frames_every_store_path
 test_event_from_wav_file_resamples_on_the_device = scenarios.test_event_from_wav_file_resamples_on_the_device
+test_fx_match_the_reference_classes_outputs = scenarios.test_fx_match_the_reference_classes_outputs

@@ -522,3 +522,26 @@ def test_event_from_wav_file_resamples_on_the_device(tmp_path):
     wavfile.write(path, sr, pcm)
     ev2 = core.Event.from_file(path, "event001", sr, augmentations=[aug.Gain(gain_db=-3.0)])
     assert ev2.clip_source().host is not None and ev2.duration == pytest.approx(len(pcm) / sr)
+
+
+def test_fx_match_the_reference_classes_outputs():
+    """G11: the product's Fade / Invert / Reverse / TimeWarp* classes against what the reference's own classes returned for
+    the same constructor arguments, input and Python random seed (tests/golden/make_fx_golden.py): float32 arithmetic on
+    the device, so exact for the permutation FX and within float32 rounding of the float64 gain curves for Fade."""
+    import os
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_fx_vectors.npz"))
+    sr = int(z["sr"])
+    for i, case in enumerate(z["fade_cases"]):
+        a, b, la, lb, src = str(case).split(",")
+        x = z["x_short" if src == "short" else "x"]
+        got = aug.Fade(sample_rate=sr, fade_in_len=float(la), fade_out_len=float(lb), fade_in_shape=a, fade_out_shape=b)(x)
+        assert got.shape == x.shape and got.dtype == np.float32
+        np.testing.assert_allclose(got, z[f"fade_{i}"], rtol=0, atol=3e-7, err_msg=str(case))
+    np.testing.assert_array_equal(aug.Invert(sample_rate=sr)(z["x"]), z["invert"])
+    np.testing.assert_array_equal(aug.Reverse(sample_rate=sr)(z["x"]), z["reverse"])
+    for i, case in enumerate(z["tw_cases"]):
+        name, fps, prob, src, seed = str(case).split(",")
+        fx = getattr(aug, name)(sample_rate=sr, fps=float(fps), prob=float(prob))
+        random.seed(int(seed))
+        np.testing.assert_array_equal(fx(z[src]), z[f"tw_{i}"].astype(np.float32), err_msg=str(case))

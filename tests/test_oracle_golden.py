@@ -3,6 +3,8 @@
 The golden vectors were produced by importing /root/reference (tests/golden/make_golden.py).
 Tolerance: the oracle is float64 like the reference, so 1e-10 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -182,3 +184,36 @@ def test_g10_stft_intermediates():
     # full chain: STFT-domain convolution restated literally == reference istft output
     got = orc.convolve_moving_stft(a, h, len(a) / 8000, 8000)
     assert rel_rms(got.T, z["g10_istft"]) < 1e-9
+
+
+def _fx_cases():
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_fx_vectors.npz"))
+    return z, int(z["sr"])
+
+
+def test_g11_reference_fx_vectors_pin_the_oracle():
+    """G11 (tests/golden/make_fx_golden.py): Fade (every shape, fades longer than the clip), Invert, Reverse and the four
+    TimeWarp classes as the reference's OWN numpy code computes them (augmentation.py:1403-1790), through
+    Augmentation.process' wrap contract.  The oracle's restatements must reproduce them exactly (float64 arithmetic on
+    the same float32 input)."""
+    import random
+
+    z, sr = _fx_cases()
+    for i, case in enumerate(z["fade_cases"]):
+        a, b, la, lb, src = str(case).split(",")
+        x = z["x_short" if src == "short" else "x"]
+        want = z[f"fade_{i}"]
+        got = orc.fx_wrap(lambda v: orc.fx_fade(v, sr, float(la), float(lb), a, b), x)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-15, err_msg=str(case))
+    np.testing.assert_array_equal(orc.fx_wrap(orc.fx_invert, z["x"]), z["invert"])
+    np.testing.assert_array_equal(orc.fx_wrap(orc.fx_reverse, z["x"]), z["reverse"])
+    modes = {"TimeWarpSilence": "silence", "TimeWarpDuplicate": "duplicate", "TimeWarpRemove": "remove", "TimeWarpReverse": "reverse"}
+    for i, case in enumerate(z["tw_cases"]):
+        name, fps, prob, src, seed = str(case).split(",")
+        x = z[src]
+        fl = round(sr / float(fps))
+        rows = 1 if fl > len(x) else fl
+        random.seed(int(seed))
+        decisions = [random.random() < float(prob) for _ in range(rows)]
+        got = orc.fx_wrap(lambda v: orc.fx_timewarp(v, sr, float(fps), decisions, modes[name]), x)
+        np.testing.assert_array_equal(got, z[f"tw_{i}"], err_msg=str(case))

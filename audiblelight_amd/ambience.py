@@ -10,6 +10,7 @@ the tiling of file-based ambience.
 """
 from __future__ import annotations
 
+import random
 from pathlib import Path
 from typing import Any, Iterable, Optional, Union
 
@@ -141,15 +142,28 @@ class Ambience:
         return self.audio is not None and valid_audio(self.audio)
 
     def _decode(self) -> np.ndarray:
+        """(file channels, samples) float32 at ``self.sample_rate`` (``librosa.load(path, sr=..., mono=False)``,
+        ambience.py:171-174).  WAV only (decoding other containers is the host decoder's business); integer PCM scaled like
+        libsndfile, another sample rate resampled on the device (ingest.resample_irs: polyphase FIR pinned to
+        scipy.signal.resample_poly)."""
         if self.clip is not None:
             return self.clip
-        from scipy.io import wavfile  # WAV only: decoding/resampling other formats is out of scope here
+        from scipy.io import wavfile
+
+        from . import ingest
 
         sr, data = wavfile.read(self.filepath)
-        if sr != self.sample_rate:
-            raise ValueError(f"Ambience file is {sr} Hz but the Ambience wants {self.sample_rate} Hz (resample upstream)")
-        data = data.astype(np.float32) / (np.iinfo(data.dtype).max if np.issubdtype(data.dtype, np.integer) else 1.0)
-        return np.atleast_2d(data.T if data.ndim == 2 else data)
+        if data.dtype == np.uint8:
+            data = (data.astype(np.float32) - 128.0) / 128.0
+        elif np.issubdtype(data.dtype, np.integer):
+            data = data.astype(np.float32) / float(2 ** (8 * data.dtype.itemsize - 1))
+        data = np.atleast_2d(np.asarray(data, dtype=np.float32).T if data.ndim == 2 else np.asarray(data, dtype=np.float32))
+        if int(sr) != self.sample_rate:
+            n_out = ingest.resampled_length(data.shape[1], sr, self.sample_rate)   # librosa.resample: ceil(n * ratio)
+            res = ingest.resample_irs(_renderer(), data, int(sr), self.sample_rate)
+            data = np.zeros((data.shape[0], n_out), dtype=np.float32)
+            data[:, : min(n_out, res.shape[1])] = res[:, :n_out]
+        return data
 
     def load_ambience_device(self, renderer=None, ignore_cache: bool = False, normalize: bool = True):
         """(channels*samples) float32 device buffer of the ambience; cached."""
@@ -165,7 +179,7 @@ class Ambience:
         else:
             src = self._decode()
             if src.shape[0] != self.channels:
-                row = 0 if src.shape[0] == 1 else int(np.random.choice(src.shape[0]))  # ambience.py:183-192
+                row = 0 if src.shape[0] == 1 else random.choice(range(src.shape[0]))  # Python's global RNG, ambience.py:183-192
                 src = np.repeat(src[row: row + 1], self.channels, axis=0)
             dev = r.mem.empty(self.channels * total)
             for c in range(self.channels):  # np.tile along time (ambience.py:204-208)

@@ -66,6 +66,23 @@ def main():
             out[f"tw_{len(tw)}"] = fx(out[src_name])
             tw.append(f"{name},{fps},{prob},{src_name},{seed}")
     out["tw_cases"] = np.array(tw)
+    # G12: Ambience in file mode (ambience.py:170-214).  Decoding is librosa's business (absent): librosa.load is replaced by a
+    # function that hands back the array below, so the vectors pin the reference's OWN channel selection, tiling along
+    # channels and time, truncation and per-channel peak normalisation.
+    import audiblelight.ambience as ref_amb
+
+    clip3 = (rng.standard_normal((3, 1700)) * np.array([[0.3], [0.6], [0.9]])).astype(np.float32)
+    out["amb_clip3"] = clip3
+    amb_cases = []
+    for j, (rows, channels, duration, seed) in enumerate([(1, 4, 0.5, 5), (3, 3, 0.6, 6), (3, 2, 0.33, 7), (3, 4, 0.1, 8)]):
+        src = clip3[:rows]
+        ref_amb.librosa.load = lambda *a, _src=src, **k: (_src if _src.shape[0] > 1 else _src[0], sr)
+        amb = ref_amb.Ambience(channels=channels, duration=duration, alias=f"amb{j}", filepath=__file__, sample_rate=sr)
+        random.seed(seed)
+        out[f"amb_{j}"] = np.asarray(amb.load_ambience(ignore_cache=True, normalize=True))
+        out[f"amb_raw_{j}"] = np.asarray(amb.load_ambience(ignore_cache=True, normalize=False)) if rows != 3 or channels == 3 else np.zeros(0)
+        amb_cases.append(f"{rows},{channels},{duration},{seed}")
+    out["amb_cases"] = np.array(amb_cases)
     path = os.path.join(HERE, "reference_fx_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: getattr(v, "shape", None) for k, v in out.items() if k.startswith(("fade_0", "tw_0", "inv"))},

@@ -54,3 +54,4 @@ def test_large_noise_lengths_statistics():
 test_encode_frames_every_store_path = scenarios.test_encode_frames_every_store_path
 test_event_from_wav_file_resamples_on_the_device = scenarios.test_event_from_wav_file_resamples_on_the_device
 test_fx_match_the_reference_classes_outputs = scenarios.test_fx_match_the_reference_classes_outputs
+test_ambience_file_mode_matches_the_reference = scenarios.test_ambience_file_mode_matches_the_reference

@@ -545,3 +545,40 @@ def test_fx_match_the_reference_classes_outputs():
         fx = getattr(aug, name)(sample_rate=sr, fps=float(fps), prob=float(prob))
         random.seed(int(seed))
         np.testing.assert_array_equal(fx(z[src]), z[f"tw_{i}"].astype(np.float32), err_msg=str(case))
+
+
+def test_ambience_file_mode_matches_the_reference(tmp_path):
+    """G12: Ambience from a clip / file (ambience.py:170-214) against the reference's own load_ambience: mono tiled over
+    channels and time, matching channel counts tiled over time only, a mismatched multichannel file reduced to one channel
+    drawn with Python's random (same seed, same channel), truncation to round(duration * sr), per-channel peak
+    normalisation.  Then the same from a PCM_16 WAV file at another sample rate (decode + device resampling)."""
+    import os
+
+    from scipy.io import wavfile
+    from scipy.signal import resample_poly
+
+    from audiblelight_amd import ambience as amb_mod
+
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_fx_vectors.npz"))
+    sr, clip3 = int(z["sr"]), z["amb_clip3"]
+    for j, case in enumerate(z["amb_cases"]):
+        rows, channels, duration, seed = str(case).split(",")
+        a = amb_mod.Ambience(channels=int(channels), duration=float(duration), alias=f"amb{j}", clip=clip3[: int(rows)], sample_rate=sr)
+        random.seed(int(seed))
+        got = a.load_ambience(ignore_cache=True, normalize=True)
+        want = z[f"amb_{j}"]
+        assert got.shape == want.shape
+        np.testing.assert_allclose(got, want, rtol=0, atol=2e-7, err_msg=str(case))
+        if z[f"amb_raw_{j}"].size:
+            np.testing.assert_array_equal(a.load_ambience(ignore_cache=True, normalize=False), z[f"amb_raw_{j}"])
+    # a stereo PCM_16 file at 6 kHz for an 8 kHz, 2-channel ambience
+    pcm = np.clip(np.rint(clip3[:2].T * 0.5 * 32767), -32768, 32767).astype(np.int16)
+    path = str(tmp_path / "amb.wav")
+    wavfile.write(path, 6000, pcm)
+    a = amb_mod.Ambience(channels=2, duration=0.7, alias="file", filepath=path, sample_rate=sr)
+    got = a.load_ambience(normalize=False)
+    src = resample_poly(pcm.T.astype(np.float64) / 32768.0, 4, 3, axis=-1)
+    n_src = int(np.ceil(pcm.shape[0] * sr / 6000))
+    src = np.pad(src, ((0, 0), (0, max(0, n_src - src.shape[1]))))[:, :n_src]
+    want = np.tile(src, (1, -(-5600 // n_src)))[:, :5600]
+    assert got.shape == (2, 5600) and rel_rms(got, want) < 1e-5

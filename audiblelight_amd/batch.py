@@ -85,7 +85,7 @@ class BatchDriver:
         dev = self.r.mem.device
         self.copy_stream = self.torch.cuda.Stream(device=dev)
         self.down_stream = self.torch.cuda.Stream(device=dev)
-        self._pinned = {}   # (tag, dtype, numel) -> list of reusable pinned host tensors (page-locking is slow)
+        self._pinned = {}   # (tag, dtype) -> {slot: reusable page-locked host tensor}
         self._slot_ready = {}   # slot -> H2D event of the scene that last used the slot's pinned clip buffer
         # default: the runtime's pageable copy (holds this thread); AL_H2D=async: page-lock in place + asynchronous DMA
         # AL_D2H=kernel: the encode / copy kernels store straight into page-locked host memory instead of a DMA on the
@@ -95,11 +95,17 @@ class BatchDriver:
         self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
-        key = (tag, dtype, int(numel))
-        pool = self._pinned.setdefault(key, [])
-        while len(pool) <= slot:
-            pool.append(self.torch.empty(int(numel), dtype=dtype).pin_memory())
-        return pool[slot]
+        """Reused page-locked host buffer of at least ``numel`` elements (a view of exactly ``numel``).  Page-locking costs
+        tens of milliseconds, so buffers are kept per (tag, slot) and only ever grow, by at least a quarter: scenes of a
+        dataset rarely have the same total clip length twice."""
+        key = (tag, dtype)
+        pool = self._pinned.setdefault(key, {})
+        buf = pool.get(slot)
+        if buf is None or buf.numel() < numel:
+            cap = max(int(numel), 0 if buf is None else buf.numel() * 5 // 4)
+            cap = (cap + 65535) // 65536 * 65536
+            buf = pool[slot] = self.torch.empty(cap, dtype=dtype).pin_memory()
+        return buf[: int(numel)]
 
     # -- stage 1a: host planning + clip packing into page-locked memory (CPU only)
     def _plan(self, job: SceneJob, slot: int = 0):
@@ -415,7 +421,7 @@ def scene_jobs(scene, name: str, renderer: Optional[engine.Renderer] = None) -> 
 
 def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True, subtype: str = "PCM_16",
                    audio_fname: str = "audio_out", metadata_fname: str = "metadata_out", metadata_json: bool = True,
-                   driver: Optional[BatchDriver] = None) -> BatchReport:
+                   driver: Optional[BatchDriver] = None, rank: int = 0, world_size: int = 1) -> BatchReport:
     """The reference's dataset loops on the pipelined driver (scripts/generate/benchmark.py:35-82,
     scripts/generate/generate_with_random_events.py:222-238, scripts/seld/generate_dataset.py:96-260).
 
@@ -423,8 +429,16 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     scenes that are actually rendered).  Layout, as ``make_a_scene`` leaves it: ``<output_dir>/<name>/
     <audio_fname>_<mic>.wav`` ((T, C) frames, soundfile's default PCM_16 unless ``subtype="FLOAT"``) and
     ``<metadata_fname>.json`` = ``scene.to_dict()`` plus ``"time"`` (seconds from staging to the file on disk).
-    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55)."""
+    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55).
+
+    ``rank`` / ``world_size``: one process per GPU, every process handed the SAME scene stream; process ``rank`` renders
+    scenes ``rank, rank + world_size, ...`` of it (``distributed.shard_stream``) into the shared ``output_dir``.  Scenes
+    are independent, so there is no collective and no factory of another rank's scene is ever called."""
     import json
+
+    from . import distributed
+
+    scenes = distributed.shard_stream(scenes, rank, world_size)
 
     driver = driver or BatchDriver(subtype=subtype)
     os.makedirs(output_dir, exist_ok=True)

@@ -19,6 +19,16 @@ def shard_indices(n_items: int, rank: int, world_size: int) -> List[int]:
     return list(range(rank, n_items, world_size))
 
 
+def shard_stream(items, rank: int, world_size: int):
+    """The same round-robin ownership for a stream of unknown length (a generator of scenes): yields items
+    ``rank, rank + world_size, ...`` and drops the others unevaluated."""
+    if not 0 <= rank < world_size:
+        raise ValueError(f"rank {rank} outside world of {world_size}")
+    for i, item in enumerate(items):
+        if i % world_size == rank:
+            yield item
+
+
 def init_process_group(backend: Optional[str] = None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
     import os

@@ -1,5 +1,7 @@
 """BASELINE.json configs[2..4] as parity cases (reduced sizes the oracle finishes in seconds):
 moving sources (cfg3), a multi-scene batch in one launch sequence (cfg4), 64 capsules + ambience + folded FX (cfg5)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -229,6 +231,16 @@ def test_render_dataset_layout_and_audio(gpu, tmp_path):
                 assert rel_rms(wav.T, want) < TOL
         again = batch.render_dataset(((f"scene_{i:03d}", factory(i)) for i in range(4)), str(tmp_path), subtype="FLOAT")
         assert again.n_scenes == 2 and built == [0, 1, 2, 3] and sorted(again.skipped) == ["scene_000", "scene_001", "scene_002"]
+        # one process per GPU, same stream of scenes: rank r renders every world_size-th scene into the shared folder and
+        # never builds the others (two "ranks" run one after the other here; there is no collective to wait for)
+        del built[:]
+        shared = tmp_path / "sharded"
+        stream = lambda: ((f"scene_{i:03d}", factory(10 + i)) for i in range(5))  # noqa: E731
+        r0 = batch.render_dataset(stream(), str(shared), subtype="FLOAT", rank=0, world_size=2)
+        assert built == [10, 12, 14] and r0.n_scenes == 6
+        r1 = batch.render_dataset(stream(), str(shared), subtype="FLOAT", rank=1, world_size=2)
+        assert built == [10, 12, 14, 11, 13] and r1.n_scenes == 4
+        assert sorted(os.listdir(shared)) == [f"scene_{i:03d}" for i in range(5)]
     finally:
         syn.set_renderer(None)
 

@@ -181,3 +181,16 @@ int main(void) { printf("%zu %zu %zu %zu\n", sizeof(al_event), sizeof(al_stream)
         subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", out])
         sizes = [int(x) for x in subprocess.check_output([out], text=True).split()]
     assert sizes == [_hip.EVENT_DTYPE.itemsize, _hip.STREAM_DTYPE.itemsize, ct.sizeof(_hip.AlBatch), ct.sizeof(_hip.AlMix)]
+
+
+def test_shard_stream_is_lazy_round_robin():
+    """distributed.shard_stream: rank r of w gets items r, r + w, ... of a generator; the ranks cover it disjointly."""
+    from audiblelight_amd import distributed
+
+    seen = [list(distributed.shard_stream(iter(range(11)), r, 3)) for r in range(3)]
+    assert seen == [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8]]
+    assert sorted(sum(seen, [])) == list(range(11))
+    import pytest as _pytest
+
+    with _pytest.raises(ValueError):
+        list(distributed.shard_stream(range(3), 2, 2))

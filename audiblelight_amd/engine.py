@@ -56,20 +56,19 @@ class TorchMemory:
         for inputs that have to be packed on the host anyway (the clips of a scene).  A fresh pageable buffer would cost
         a page fault per 4 KiB before the copy even starts."""
         if not hasattr(self, "_staging"):
-            self._staging = {}
-        key = int(n)
-        if key not in self._staging:
-            if len(self._staging) >= 4:          # a few scene shapes at most; drop the oldest
-                self._staging.pop(next(iter(self._staging)))
-            self._staging[key] = [self.torch.empty(key, dtype=self.torch.float32, pin_memory=True), None]
-        host, last = self._staging[key]
+            self._staging = [None, None]         # [page-locked buffer that only grows, event of the last DMA out of it]
+        host, last = self._staging
         if last is not None:
             last.synchronize()                   # the previous DMA out of this buffer must have finished
-        fill(host.numpy())
-        dev = host.to(self.device, non_blocking=True)
+        if host is None or host.numel() < n:     # page-locking costs tens of ms: grow by at least a quarter, never per size
+            cap = max(int(n), 0 if host is None else host.numel() * 5 // 4)
+            host = self._staging[0] = self.torch.empty((cap + 65535) // 65536 * 65536, dtype=self.torch.float32, pin_memory=True)
+        view = host[: int(n)]
+        fill(view.numpy())
+        dev = view.to(self.device, non_blocking=True)
         ev = self.torch.cuda.Event()
         ev.record(self.torch.cuda.current_stream(self.device))
-        self._staging[key][1] = ev
+        self._staging[1] = ev
         return dev
 
     def upload_async(self, arr: np.ndarray):

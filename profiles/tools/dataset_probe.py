@@ -26,3 +26,14 @@ t2 = time.perf_counter()
 pr.disable()
 print("make_scene %.1f ms, scene_jobs %.1f ms per scene" % ((t1 - t0) / 20 * 1e3, ((t2 - t1) - (t1 - t0)) / 20 * 1e3))
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+# the synchronous API in a loop (what a reference user's script does): Scene.generate per scene
+for i in range(4):
+    ex.make_scene(200 + i).generate(output_dir=os.path.join(out, f"g{i}"))
+pr = cProfile.Profile(); pr.enable()
+t0 = time.perf_counter()
+for i in range(30):
+    ex.make_scene(300 + i).generate(output_dir=os.path.join(out, f"h{i}"))
+dt = time.perf_counter() - t0
+pr.disable()
+print("Scene.generate loop: %.1f ms/scene" % (dt / 30 * 1e3))
+pstats.Stats(pr).sort_stats("tottime").print_stats(14)

@@ -230,12 +230,13 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
 // table reads) and the dispatch of 32x as many workgroups disappear, and because nothing waits on X any more the
 // partition spectrum h[p] of the NEXT capsule is requested the moment the last product with h[p] of this one has been
 // issued -- the H stream, the FMAs and the Y stores of consecutive capsules overlap inside one wave.
-// MASKH: the partition count is not a multiple of PT, so a tile can hold partitions that do not exist (read clamped,
-// zeroed by a uniform multiply); with P % PT == 0 every h[pp] is a real partition and no mask exists in the loop.
+// PT is the batch's partition count itself (one instantiation per P = 1..12): every h[pp] is a real partition, nothing in the
+// loop is masked.  (A 12-wide tile with the missing partitions zeroed by a multiply, selected from a zero block or skipped by
+// a uniform branch spilled 104-192 B per lane and ran 25-70 % slower than the tile kernels at P = 10, profiles/r02_mac.txt.)
 // NKTW: k-tiles per workgroup (256 threads each).  Two k-tiles of one (event, bin tile) read the SAME partition spectra;
 // in one workgroup, kept in step by a barrier per capsule, the second read of every line is an L1 hit on the same CU
 // instead of a second trip to L2 / HBM by another workgroup that may have drifted away.
-template <int KT, int PT, bool BIN0, bool MASKH, int NKTW>
+template <int KT, int PT, bool BIN0, int NKTW>
 __device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
   using V = BinVec<2>;
   constexpr int NJ = KT + PT - 1;
@@ -272,11 +273,7 @@ __device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
       xw[jj].scale((j >= jlo && j < jhi) ? g : 0.f);
     }
   };
-  auto h_load = [&](int c, int p) {
-    V v = V::load(H + ((int64_t)c * P + min(p, P - 1)) * M);
-    if constexpr (MASKH) v.scale(p <= phi ? 1.f : 0.f);        // uniform
-    return v;
-  };
+  auto h_load = [&](int c, int p) { return V::load(H + ((int64_t)c * P + min(p, P - 1)) * M); };
   V h[PT];
   if (single && active) {
     load_window(plo);
@@ -311,10 +308,10 @@ __device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
   }
 }
 
-template <int KT, int PT, bool MASKH, int NKTW>
+template <int KT, int PT, int NKTW>
 __global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch b) {
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_body<KT, PT, true, MASKH, NKTW>(b);
-  else spectral_mac_static_body<KT, PT, false, MASKH, NKTW>(b);
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_body<KT, PT, true, NKTW>(b);
+  else spectral_mac_static_body<KT, PT, false, NKTW>(b);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events
@@ -975,12 +972,9 @@ int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *mo
   if (int rc = check_batch(b)) return rc;
   if (!static_code || !moving_code) return fail(AL_E_BADARG, "null output");
   pick_mac(b, static_code, moving_code);
-  // one-emitter events through k_spectral_mac_static<12, PT, MASKH, NKTW>: 3000000 + 10000*12 + 100*PT + 10*MASKH + NKTW
+  // one-emitter events through k_spectral_mac_static<12, PT = P, NKTW>: 3000000 + 10000*12 + 100*PT + NKTW
   // (the tile kernel pick_mac names then only sees multi-emitter events, if the batch has any)
-  if (al::static_mac_active(*b)) {
-    const int P = b->n_partitions, PT = P <= 6 ? 6 : 12;
-    *static_code = 3000000 + 120000 + 100 * PT + 10 * (P % PT != 0 ? 1 : 0) + (static_pair(b) ? 2 : 1);
-  }
+  if (al::static_mac_active(*b)) *static_code = 3000000 + 120000 + 100 * b->n_partitions + (static_pair(b) ? 2 : 1);
   return AL_OK;
 }
 
@@ -1001,18 +995,15 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
     const int P = b->n_partitions;
     const bool pair = static_pair(b);
     const dim3 grid(bins / 512, pair ? (n_ktiles + 1) / 2 : n_ktiles, b->n_events * n_cs);
-#define AL_STATIC(PT_, MASK_) \
-    do { \
-      if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, MASK_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
-      else hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, MASK_, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b); \
-    } while (0)
-    if (P <= 6) {
-      if (P == 6) AL_STATIC(6, false);
-      else AL_STATIC(6, true);
-    } else if (P % 12 == 0) {
-      AL_STATIC(12, false);
-    } else {
-      AL_STATIC(12, true);
+#define AL_STATIC(PT_) \
+    case PT_: \
+      if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
+      else hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b); \
+      break
+    switch (P) {   // the partition tile IS the partition count: no masked partitions in the loop
+      AL_STATIC(1); AL_STATIC(2); AL_STATIC(3); AL_STATIC(4); AL_STATIC(5); AL_STATIC(6);
+      AL_STATIC(7); AL_STATIC(8); AL_STATIC(9); AL_STATIC(10); AL_STATIC(11); AL_STATIC(12);
+      default: return fail(AL_E_BADARG, "capsule-loop accumulate: more than 12 partitions");
     }
 #undef AL_STATIC
     if (int rc = check_launch("k_spectral_mac_static")) return rc;

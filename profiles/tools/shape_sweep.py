@@ -10,7 +10,7 @@ base = dict(C=32, E=64, La=192000, Lir=96000)
 sweeps = [("base", {})] + [("La", dict(La=v)) for v in (48000, 100000, 160000, 400000, 960000)] + \
          [("Lir", dict(Lir=v)) for v in (4000, 30000, 100000, 110000, 150000, 192000)] + \
          [("C", dict(C=v)) for v in (1, 4, 19, 64)] + [("E", dict(E=v)) for v in (1, 4, 16)] + \
-         [("ragged", dict(ragged=True))]
+         [("ragged", dict(ragged=True)), ("odd", dict(La=191999)), ("odd", dict(La=191997, Lir=95999))]
 for name, over in sweeps:
     p = dict(base, **over)
     C, E, La, Lir = p["C"], p["E"], p["La"], p["Lir"]

@@ -314,6 +314,106 @@ __global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch 
   else spectral_mac_static_body<KT, PT, false, NKTW>(b);
 }
 
+// Variant of the two-k-tile workgroup for clips of more than 24 blocks (several workgroups per (event, bin tile), all reading
+// the same partition spectra): the 512 threads copy the (PT x 512 slot) tile of capsule c+2 into a ring of three LDS stages
+// while capsule c is multiplied, so H enters the CU once instead of twice (the second k-tile's L1 hit) and no partition
+// spectrum waits in registers.  Equal to the register version at K <= 24, 8-10 % faster beyond (profiles/r02_mac.txt 10).
+template <int KT, int PT, bool BIN0>
+__device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, float4 *hbuf) {
+  using V = BinVec<2>;
+  constexpr int NJ = KT + PT - 1, STAGE = PT * 256, PER = (STAGE + 511) / 512;
+  const int M = 1 << b.log2_block;
+  const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8;
+  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int n_cs = gridDim.z / b.n_events;
+  const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
+  const al_event ev = b.events[b.event0 + e];
+  if (ev.n_streams != 1) return;
+  const int K = ev.n_blocks, P = b.n_partitions, C = b.n_capsules;
+  const int k0 = (blockIdx.y * 2 + sub) * KT;
+  const bool active = k0 < K;
+  const int c_begin = (int)((int64_t)cs * C / n_cs), c_end = (int)((int64_t)(cs + 1) * C / n_cs);
+  const al_stream st = b.streams[ev.stream0];
+  const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
+  const bool packed = (f == 0);
+  const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
+  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + blockIdx.x * 512;
+  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + k0) * M + f;
+  const float g = b.emitter_gain[st.emitter];
+  V xw[NJ];
+  if (active) {
+    const int jbase = k0 - (PT - 1);
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) {
+      const int j = jbase + jj;
+      xw[jj] = V::load(X + (int64_t)min(max(j, jlo), jhi - 1) * M);
+      xw[jj].scale((j >= jlo && j < jhi) ? g : 0.f);
+    }
+  }
+  static_assert(PER <= 6, "staging registers are named, not indexed (an indexed array stayed in scratch memory)");
+  float4 g0, g1, g2, g3, g4, g5;
+  g0 = g1 = g2 = g3 = g4 = g5 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define AL_FETCH1(R, I, CAPSULE)                                                                                             \
+  if ((I) < PER && (STAGE % 512 == 0 || (int)threadIdx.x + 512 * (I) < STAGE))                                               \
+    R = *reinterpret_cast<const float4 *>(Htile + ((int64_t)(CAPSULE) * P + (((int)threadIdx.x + 512 * (I)) >> 8)) * M +    \
+                                          (((int)threadIdx.x + 512 * (I)) & 255) * 2);
+#define AL_FETCH(CAPSULE)                                                                                                    \
+  { const int cc_ = (CAPSULE); AL_FETCH1(g0, 0, cc_) AL_FETCH1(g1, 1, cc_) AL_FETCH1(g2, 2, cc_) AL_FETCH1(g3, 3, cc_)       \
+    AL_FETCH1(g4, 4, cc_) AL_FETCH1(g5, 5, cc_) }
+#define AL_STASH1(R, I, S)                                                                                                   \
+  if ((I) < PER && (STAGE % 512 == 0 || (int)threadIdx.x + 512 * (I) < STAGE)) hbuf[(S) * STAGE + threadIdx.x + 512 * (I)] = R;
+#define AL_STASH(STAGE_INDEX)                                                                                                \
+  { const int ss_ = (STAGE_INDEX); AL_STASH1(g0, 0, ss_) AL_STASH1(g1, 1, ss_) AL_STASH1(g2, 2, ss_) AL_STASH1(g3, 3, ss_)   \
+    AL_STASH1(g4, 4, ss_) AL_STASH1(g5, 5, ss_) }
+  AL_FETCH(c_begin)
+  AL_STASH(0)
+  AL_FETCH(min(c_begin + 1, c_end - 1))
+  AL_STASH(1)
+  for (int c = c_begin; c < c_end; ++c) {
+    const int it = c - c_begin, cur = it % 3, nxt = (it + 2) % 3;
+    AL_FETCH(min(c + 2, c_end - 1))                             // in flight during this capsule's products (the last two
+                                                                // iterations re-fetch the last capsule: unconditional code)
+    __syncthreads();                                            // stage `cur` is complete, stage `nxt` is no longer read
+    if (active) {
+      V acc[KT];
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
+      const float4 *hs = hbuf + cur * STAGE + lane256;
+      float4 hv = hs[0], hn = hv;
+      static_for<PT>([&](auto pp_c) {
+        constexpr int pp = decltype(pp_c)::value;
+        if constexpr (pp + 1 < PT) {                            // the next partition's LDS read is issued before this one's
+          hn = hs[(pp + 1) * 256];                              // products, not a few instructions before its first use
+#if defined(__HIP_DEVICE_COMPILE__)
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        const V h{make_float2(hv.x, hv.y), make_float2(hv.z, hv.w)};
+        static_for<KT>([&](auto kk_c) {
+          constexpr int kk = decltype(kk_c)::value;
+          acc[kk].template fma_packed<BIN0>(xw[kk + (PT - 1) - pp], h, packed);
+        });
+        hv = hn;
+      });
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk)
+        if (k0 + kk < K) acc[kk].store(Y + ((int64_t)c * K + kk) * M);
+    }
+    AL_STASH(nxt)
+  }
+#undef AL_FETCH
+#undef AL_STASH
+#undef AL_FETCH1
+#undef AL_STASH1
+}
+
+template <int KT, int PT>
+__global__ __launch_bounds__(512, 2) void k_spectral_mac_static_lds(al_batch b) {
+  __shared__ float4 hbuf[3 * PT * 256];
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, true>(b, hbuf);
+  else spectral_mac_static_lds_body<KT, PT, false>(b, hbuf);
+}
+
 // ------------------------------------------------------------------ 4b. accumulate for moving events
 // A moving event is N streams (one per IR) whose clips are only a few blocks long (the cross-fade window of
 // that IR) and whose first blocks j_lo are non-decreasing.  One thread owns one bin (pair) of one capsule and
@@ -974,7 +1074,11 @@ int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *mo
   pick_mac(b, static_code, moving_code);
   // one-emitter events through k_spectral_mac_static<12, PT = P, NKTW>: 3000000 + 10000*12 + 100*PT + NKTW
   // (the tile kernel pick_mac names then only sees multi-emitter events, if the batch has any)
-  if (al::static_mac_active(*b)) *static_code = 3000000 + 120000 + 100 * b->n_partitions + (static_pair(b) ? 2 : 1);
+  // NKTW digit: 1 = one k-tile per workgroup, 2 = two, 3 = two with the partition spectra staged through LDS (more than 24 blocks)
+  if (al::static_mac_active(*b)) {
+    const bool lds_ring = static_pair(b) && (b->max_blocks + 23) / 24 > 1 && !(b->flags & (1 << 13));
+    *static_code = 3000000 + 120000 + 100 * b->n_partitions + (lds_ring ? 3 : static_pair(b) ? 2 : 1);
+  }
   return AL_OK;
 }
 
@@ -995,12 +1099,14 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
     const int P = b->n_partitions;
     const bool pair = static_pair(b);
     const dim3 grid(bins / 512, pair ? (n_ktiles + 1) / 2 : n_ktiles, b->n_events * n_cs);
+    const bool lds_ring = pair && grid.y > 1 && !(b->flags & (1 << 13));   // flags bit 13: A/B switch, register version
+    switch (P) {   // the partition tile IS the partition count: no masked partitions in the loop
 #define AL_STATIC(PT_) \
     case PT_: \
-      if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
+      if (lds_ring) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT_>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
+      else if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
       else hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b); \
       break
-    switch (P) {   // the partition tile IS the partition count: no masked partitions in the loop
       AL_STATIC(1); AL_STATIC(2); AL_STATIC(3); AL_STATIC(4); AL_STATIC(5); AL_STATIC(6);
       AL_STATIC(7); AL_STATIC(8); AL_STATIC(9); AL_STATIC(10); AL_STATIC(11); AL_STATIC(12);
       default: return fail(AL_E_BADARG, "capsule-loop accumulate: more than 12 partitions");

@@ -178,7 +178,8 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequenc
 /* Which kernel instantiations al_spectral_mac launches for this batch (no launch; used by the parity tests to assert
  * the regime they cover).  *static_code = the kernel that takes one-emitter events: 1000000*KSPLIT + 10000*KT + 100*PT + VB
  * (k-tile, partition tile, bins per thread of the tile kernel), or 3120000 + 100*PT + NKTW for the capsule-loop
- * kernel k_spectral_mac_static<12, PT = partitions, k-tiles per workgroup> (AL_FLAG_STATIC_MAC and at most 12 partitions); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
+ * kernel k_spectral_mac_static<12, PT = partitions, k-tiles per workgroup> (NKTW digit 3: two k-tiles with the partition
+ * spectra staged through LDS, k_spectral_mac_static_lds, clips of more than 24 blocks) (AL_FLAG_STATIC_MAC and at most 12 partitions); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 /* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.

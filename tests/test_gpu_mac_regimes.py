@@ -30,12 +30,14 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block == 13))
 
 
-STATIC_LOOP_CASES = [   # (name, expected code 3120000 + 100*PT + NKTW with PT = the partition count, K multiple, P multiple, capsules, events)
+STATIC_LOOP_CASES = [   # (name, expected code 3120000 + 100*PT + {1, 2, 3 = two k-tiles with H staged through LDS} with PT = the partition count, K multiple, P multiple, capsules, events)
     ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
     ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
     ("one_ktile_full6", 3120601, 10.0006, 5.002, 4, 3),        # K = 11, P = 6 = PT
     ("one_ktile_masked6", 3120301, 6.5, 2.5, 3, 1),            # K = 7, P = 3; one event: capsule ranges split
-    ("three_ktiles_idle_half", 3121202, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles, the last workgroup has an idle half
+    ("three_ktiles_idle_half", 3121203, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles in 2 workgroups (LDS-staged H), the last has an idle half
+    ("lds_ring_odd_partitions", 3120903, 30.2, 8.6, 3, 2),     # K = 31, P = 9: the staging copy has a ragged last round
+    ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
 ]
 
 

@@ -118,7 +118,7 @@ template <> struct BinVec<2> {
 
 // k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
 __host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
-  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 12 && b.log2_block >= 9;
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 16 && b.log2_block >= 9;
 }
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
@@ -318,10 +318,12 @@ __global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch 
 // the same partition spectra): the 512 threads copy the (PT x 512 slot) tile of capsule c+2 into a ring of three LDS stages
 // while capsule c is multiplied, so H enters the CU once instead of twice (the second k-tile's L1 hit) and no partition
 // spectrum waits in registers.  Equal to the register version at K <= 24, 8-10 % faster beyond (profiles/r02_mac.txt 10).
-template <int KT, int PT, bool BIN0>
+template <int KT, int PT, int UNITS, bool BIN0>
 __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, float4 *hbuf) {
+  // UNITS = 2: 13..16 partitions as two units of PT = ceil(P / 2) per capsule (the pipeline step is a unit; for odd P the
+  // last unit's missing partition is stored as zeros in its LDS stage, so nothing in the products is masked)
   using V = BinVec<2>;
-  constexpr int NJ = KT + PT - 1, STAGE = PT * 256, PER = (STAGE + 511) / 512;
+  constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PER = (STAGE + 511) / 512;
   const int M = 1 << b.log2_block;
   const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8;
   const int f = (blockIdx.x * 256 + lane256) * 2;
@@ -342,7 +344,7 @@ __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, 
   const float g = b.emitter_gain[st.emitter];
   V xw[NJ];
   if (active) {
-    const int jbase = k0 - (PT - 1);
+    const int jbase = k0 - (PALL - 1);
 #pragma unroll
     for (int jj = 0; jj < NJ; ++jj) {
       const int j = jbase + jj;
@@ -353,53 +355,65 @@ __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, 
   static_assert(PER <= 6, "staging registers are named, not indexed (an indexed array stayed in scratch memory)");
   float4 g0, g1, g2, g3, g4, g5;
   g0 = g1 = g2 = g3 = g4 = g5 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define AL_FETCH1(R, I, CAPSULE)                                                                                             \
-  if ((I) < PER && (STAGE % 512 == 0 || (int)threadIdx.x + 512 * (I) < STAGE))                                               \
-    R = *reinterpret_cast<const float4 *>(Htile + ((int64_t)(CAPSULE) * P + (((int)threadIdx.x + 512 * (I)) >> 8)) * M +    \
-                                          (((int)threadIdx.x + 512 * (I)) & 255) * 2);
-#define AL_FETCH(CAPSULE)                                                                                                    \
-  { const int cc_ = (CAPSULE); AL_FETCH1(g0, 0, cc_) AL_FETCH1(g1, 1, cc_) AL_FETCH1(g2, 2, cc_) AL_FETCH1(g3, 3, cc_)       \
-    AL_FETCH1(g4, 4, cc_) AL_FETCH1(g5, 5, cc_) }
+  const int n_units = UNITS * (c_end - c_begin);
+  // unit n = (capsule c_begin + n / UNITS, partitions [(n % UNITS) * PT, +PT)); row r of the copy is partition p0 + r
+#define AL_FETCH1(R, I, C_, P0_)                                                                                             \
+  if ((I) < PER && (STAGE % 512 == 0 || (int)threadIdx.x + 512 * (I) < STAGE)) {                                             \
+    const int q_ = (int)threadIdx.x + 512 * (I), p_ = (P0_) + (q_ >> 8);                                                     \
+    R = (UNITS == 1 || p_ < P) ? *reinterpret_cast<const float4 *>(Htile + ((int64_t)(C_) * P + min(p_, P - 1)) * M + (q_ & 255) * 2) \
+                               : make_float4(0.f, 0.f, 0.f, 0.f);                                                            \
+  }
+#define AL_FETCH(UNIT)                                                                                                       \
+  { const int n_ = min((UNIT), n_units - 1), cc_ = c_begin + n_ / UNITS, p0_ = (n_ % UNITS) * PT;                            \
+    AL_FETCH1(g0, 0, cc_, p0_) AL_FETCH1(g1, 1, cc_, p0_) AL_FETCH1(g2, 2, cc_, p0_) AL_FETCH1(g3, 3, cc_, p0_)               \
+    AL_FETCH1(g4, 4, cc_, p0_) AL_FETCH1(g5, 5, cc_, p0_) }
 #define AL_STASH1(R, I, S)                                                                                                   \
   if ((I) < PER && (STAGE % 512 == 0 || (int)threadIdx.x + 512 * (I) < STAGE)) hbuf[(S) * STAGE + threadIdx.x + 512 * (I)] = R;
 #define AL_STASH(STAGE_INDEX)                                                                                                \
   { const int ss_ = (STAGE_INDEX); AL_STASH1(g0, 0, ss_) AL_STASH1(g1, 1, ss_) AL_STASH1(g2, 2, ss_) AL_STASH1(g3, 3, ss_)   \
     AL_STASH1(g4, 4, ss_) AL_STASH1(g5, 5, ss_) }
-  AL_FETCH(c_begin)
+  AL_FETCH(0)
   AL_STASH(0)
-  AL_FETCH(min(c_begin + 1, c_end - 1))
+  AL_FETCH(1)
   AL_STASH(1)
+  int n = 0;                                                    // unit being multiplied
   for (int c = c_begin; c < c_end; ++c) {
-    const int it = c - c_begin, cur = it % 3, nxt = (it + 2) % 3;
-    AL_FETCH(min(c + 2, c_end - 1))                             // in flight during this capsule's products (the last two
-                                                                // iterations re-fetch the last capsule: unconditional code)
-    __syncthreads();                                            // stage `cur` is complete, stage `nxt` is no longer read
-    if (active) {
-      V acc[KT];
+    V acc[KT];
 #pragma unroll
-      for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
-      const float4 *hs = hbuf + cur * STAGE + lane256;
-      float4 hv = hs[0], hn = hv;
-      static_for<PT>([&](auto pp_c) {
-        constexpr int pp = decltype(pp_c)::value;
-        if constexpr (pp + 1 < PT) {                            // the next partition's LDS read is issued before this one's
-          hn = hs[(pp + 1) * 256];                              // products, not a few instructions before its first use
+    for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
+    static_for<UNITS>([&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      const int cur = n % 3, nxt = (n + 2) % 3;
+      AL_FETCH(n + 2)                                           // in flight during this unit's products (past the end the last
+                                                                // unit is fetched again: unconditional code)
+      __syncthreads();                                          // stage `cur` is complete, stage `nxt` is no longer read
+      if (active) {
+        const float4 *hs = hbuf + cur * STAGE + lane256;
+        float4 hv = hs[0], hn = hv;
+        static_for<PT>([&](auto pp_c) {
+          constexpr int pp = decltype(pp_c)::value;
+          if constexpr (pp + 1 < PT) {                          // the next partition's LDS read is issued before this one's
+            hn = hs[(pp + 1) * 256];                            // products, not a few instructions before its first use
 #if defined(__HIP_DEVICE_COMPILE__)
-          __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_sched_barrier(0);
 #endif
-        }
-        const V h{make_float2(hv.x, hv.y), make_float2(hv.z, hv.w)};
-        static_for<KT>([&](auto kk_c) {
-          constexpr int kk = decltype(kk_c)::value;
-          acc[kk].template fma_packed<BIN0>(xw[kk + (PT - 1) - pp], h, packed);
+          }
+          const V h{make_float2(hv.x, hv.y), make_float2(hv.z, hv.w)};
+          static_for<KT>([&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            acc[kk].template fma_packed<BIN0>(xw[kk + (PALL - 1) - (u * PT + pp)], h, packed);
+          });
+          hv = hn;
         });
-        hv = hn;
-      });
+      }
+      AL_STASH(nxt)
+      ++n;
+    });
+    if (active) {
 #pragma unroll
       for (int kk = 0; kk < KT; ++kk)
         if (k0 + kk < K) acc[kk].store(Y + ((int64_t)c * K + kk) * M);
     }
-    AL_STASH(nxt)
   }
 #undef AL_FETCH
 #undef AL_STASH
@@ -407,11 +421,11 @@ __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, 
 #undef AL_STASH1
 }
 
-template <int KT, int PT>
+template <int KT, int PT, int UNITS = 1>
 __global__ __launch_bounds__(512, 2) void k_spectral_mac_static_lds(al_batch b) {
   __shared__ float4 hbuf[3 * PT * 256];
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, true>(b, hbuf);
-  else spectral_mac_static_lds_body<KT, PT, false>(b, hbuf);
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, UNITS, true>(b, hbuf);
+  else spectral_mac_static_lds_body<KT, PT, UNITS, false>(b, hbuf);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events
@@ -1076,7 +1090,7 @@ int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *mo
   // (the tile kernel pick_mac names then only sees multi-emitter events, if the batch has any)
   // NKTW digit: 1 = one k-tile per workgroup, 2 = two, 3 = two with the partition spectra staged through LDS (more than 24 blocks)
   if (al::static_mac_active(*b)) {
-    const bool lds_ring = static_pair(b) && (b->max_blocks + 23) / 24 > 1 && !(b->flags & (1 << 13));
+    const bool lds_ring = b->n_partitions > 12 || (static_pair(b) && (b->max_blocks + 23) / 24 > 1 && !(b->flags & (1 << 13)));
     *static_code = 3000000 + 120000 + 100 * b->n_partitions + (lds_ring ? 3 : static_pair(b) ? 2 : 1);
   }
   return AL_OK;
@@ -1109,7 +1123,14 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
       break
       AL_STATIC(1); AL_STATIC(2); AL_STATIC(3); AL_STATIC(4); AL_STATIC(5); AL_STATIC(6);
       AL_STATIC(7); AL_STATIC(8); AL_STATIC(9); AL_STATIC(10); AL_STATIC(11); AL_STATIC(12);
-      default: return fail(AL_E_BADARG, "capsule-loop accumulate: more than 12 partitions");
+#define AL_STATIC2(PT_) \
+    case 2 * PT_ - 1: case 2 * PT_: /* 13..16 partitions: two units of PT_ per capsule, always through LDS */ \
+      hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT_, 2>), dim3(grid.x, (n_ktiles + 1) / 2, grid.z), dim3(512), 0, \
+                         (hipStream_t)stream, *b); \
+      break
+      AL_STATIC2(7); AL_STATIC2(8);   // 17..24 partitions: the window (KT + P - 1 blocks) no longer fits beside the accumulators
+#undef AL_STATIC2
+      default: return fail(AL_E_BADARG, "capsule-loop accumulate: more than 16 partitions");
     }
 #undef AL_STATIC
     if (int rc = check_launch("k_spectral_mac_static")) return rc;

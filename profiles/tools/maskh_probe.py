@@ -5,8 +5,8 @@ import numpy as np, torch
 from audiblelight_amd import engine, synthetic, plan as planning
 sc = synthetic.make_scene("cfg2")
 r = engine.Renderer()
-for taps in (96000, 88000, 80000, 64000, 56000, 40000, 24000, 12000):
-    irs = np.ascontiguousarray(sc.irs[:, :, :taps])
+for taps in [int(t) for t in os.environ.get('TAPS', '96000,88000,80000,64000,56000,40000,24000,12000').split(',')]:
+    irs = np.ascontiguousarray(np.concatenate([sc.irs, 0.05 * sc.irs, 0.01 * sc.irs], axis=2)[:, :, :taps])
     c, n, l = irs.shape
     for static in ("1", "0"):
         os.environ["AL_STATIC_MAC"] = static

@@ -38,13 +38,16 @@ STATIC_LOOP_CASES = [   # (name, expected code 3120000 + 100*PT + {1, 2, 3 = two
     ("three_ktiles_idle_half", 3121203, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles in 2 workgroups (LDS-staged H), the last has an idle half
     ("lds_ring_odd_partitions", 3120903, 30.2, 8.6, 3, 2),     # K = 31, P = 9: the staging copy has a ragged last round
     ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
+    ("two_units_odd", 3121303, 17.3, 12.6, 3, 2),              # P = 13: two units of 7, the 14th partition is a zero LDS row
+    ("two_units_16_long", 3121603, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
+    ("two_units_one_ktile", 3121403, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
 ]
 
 
 @pytest.mark.parametrize("log2_block", [10, 13])
 @pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", STATIC_LOOP_CASES, ids=[c[0] for c in STATIC_LOOP_CASES])
 def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
-    """k_spectral_mac_static (default for one-emitter events with at most 12 partitions): every instantiation, ragged
+    """k_spectral_mac_static (default for one-emitter events with at most 16 partitions): every instantiation, ragged
     tiles, the capsule-range split of small batches; every row against the oracle."""
     monkeypatch.delenv("AL_STATIC_MAC", raising=False)
     monkeypatch.delenv("AL_FUSED", raising=False)

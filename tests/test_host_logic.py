@@ -194,3 +194,73 @@ def test_shard_stream_is_lazy_round_robin():
 
     with _pytest.raises(ValueError):
         list(distributed.shard_stream(range(3), 2, 2))
+
+
+def test_planner_invariants_on_random_scenes():
+    """Property test of the host planner over random event lists: workspace regions are disjoint and 16-byte aligned, every
+    tile of the mixdown plan lists exactly the events that overlap it, in insertion order, and the per-tile work adds up to
+    what a plain loop over the events would add (reference loop: synthesize.py:358-383)."""
+    from hypothesis import given, settings, strategies as st
+
+    from audiblelight_amd import plan as planning
+
+    event = st.tuples(st.integers(1, 40_000), st.sampled_from([0, 1, 1, 1, 3, 6]), st.floats(0.0, 9.0), st.floats(-2.0, 30.0))
+
+    @settings(max_examples=250, deadline=None)
+    @given(st.lists(event, min_size=1, max_size=7), st.integers(1, 5), st.integers(1, 9000), st.sampled_from([10, 11, 12, 13]))
+    def check(events, n_capsules, ir_len, log2_block):
+        sr, duration = 8000, 10.0
+        specs, col = [], 0
+        for n, n_emit, _, snr in events:
+            specs.append(planning.EventSpec(n_samples=n, n_emitters=n_emit, snr=snr, emitter0=col, is_moving=n_emit > 1,
+                                            duration=n / sr if n_emit > 1 else None))
+            col += n_emit
+        pl = planning.plan_batch(specs, n_capsules, ir_len, sr, log2_block=log2_block)
+        ev = pl.events
+        B = 1 << log2_block
+        assert pl.n_emitters == col and pl.n_partitions in (-(-ir_len // B), 0 if col == 0 else -1)
+        # clips and event outputs: 16-byte aligned, back to back, no overlap
+        assert (ev["audio_off"] % 4 == 0).all() and (ev["out_off"] % 4 == 0).all()
+        for a, b in zip(range(len(ev) - 1), range(1, len(ev))):
+            assert ev["audio_off"][a] + ev["len"][a] <= ev["audio_off"][b]
+            assert ev["out_off"][a] + n_capsules * ev["len"][a] <= ev["out_off"][b]
+        assert pl.audio_floats >= ev["audio_off"][-1] + ev["len"][-1] and pl.spatial_floats >= ev["out_off"][-1] + n_capsules * ev["len"][-1]
+        assert (ev["n_blocks"] == -(-ev["len"] // B)).all() and (ev["valid_len"] <= ev["len"]).all()
+        # output-spectra and statistics regions of consecutive events do not overlap
+        conv = ev["n_streams"] > 0
+        y_end = ev["yspec_base"] + n_capsules * ev["n_blocks"] * conv
+        assert (ev["yspec_base"][1:] >= y_end[:-1]).all() and pl.yspec_blocks >= int(y_end.max())
+        assert (ev["part_base"][1:] == ev["part_base"][:-1] + n_capsules * ev["n_blocks"][:-1]).all()
+        # signal-spectra runs of the streams are disjoint and inside the clip's blocks
+        runs = sorted((int(s["xspec_base"]), int(s["n_j"])) for s in pl.streams if s["n_j"] > 0)
+        for (a0, an), (b0, _) in zip(runs, runs[1:]):
+            assert a0 + an <= b0
+        for s in pl.streams:
+            assert 0 <= s["j_lo"] and s["j_lo"] + s["n_j"] <= max(int(ev["n_blocks"][s["event"]]), 1)
+        # mixdown plan against a plain loop
+        starts = [e[2] for e in events]
+        ends = [s0 + n / sr for s0, (n, *_r) in zip(starts, events)]
+        lens = [e[0] for e in events]
+        mp = planning.plan_mixdown(starts, ends, lens, [n_capsules] * len(events), ev["out_off"], list(range(len(events))),
+                                   duration, sr, n_capsules)
+        n_scene = round(duration * sr)
+        want_cover = np.zeros(n_scene, dtype=np.int64)
+        kept = []
+        for i, (t0, t1, la) in enumerate(zip(starts, ends, lens)):
+            a, b = planning.event_slot(t0, t1, sr, n_scene)
+            if b > a:
+                kept.append(i)
+                want_cover[a: a + min(b - a, la)] += 1
+        assert sorted(kept + list(mp.skipped)) == list(range(len(events))) and list(mp.slot_event[: len(kept)]) == kept
+        got_cover = np.zeros(n_scene, dtype=np.int64)
+        for t in range(mp.n_tiles):
+            slots = mp.tile_events[mp.tile_ptr[t]: mp.tile_ptr[t + 1]]
+            assert list(slots) == sorted(slots)                                   # insertion order inside a tile
+            lo, hi = t * mp.tile, min((t + 1) * mp.tile, n_scene)
+            for sl in slots:
+                a, cnt = int(mp.slot_start[sl]), int(mp.slot_count[sl])
+                assert a < hi and a + cnt > lo                                    # the slot really overlaps the tile
+                got_cover[max(a, lo): min(a + cnt, hi)] += 1
+        np.testing.assert_array_equal(got_cover, want_cover)
+
+    check()

@@ -16,3 +16,30 @@ res = r.render(pl, clips, np.concatenate(irs, axis=1), chunk_events=2)
 mix = planning.plan_mixdown([0.0, 0.1, 0.2, 0.05], [0.3, 0.4, 0.25, 0.2], [len(c) for c in clips], [C] * 4, pl.events["out_off"], [0, 1, 2, 3], 0.5, sr, C)
 scene = r.mem.download(r.mixdown(mix, res))
 print("asan run ok", float(np.abs(scene[: C * mix.n_samples]).sum()), res.scales())
+# round 2 kernels: the LDS-staged capsule loop (clip of more than 24 blocks), its two-unit form (13 partitions, the 14th a
+# zero row), rows at odd offsets (shifted-pair stores), the split spectra layout, the frame encoder's 16-byte store paths
+import ctypes as ct, os
+for lb, split in ((10, "0"), (11, "1")):
+    os.environ["AL_SPLIT"] = split
+    B = 1 << lb
+    La, Lir, C = 26 * B + 1, 13 * B - 5, 2
+    clips = [rng.standard_normal(La - 2 * e).astype(np.float32) for e in range(2)]
+    irs = (rng.standard_normal((C, 2, Lir)) * np.exp(-np.arange(Lir) / (Lir / 5.0))).astype(np.float32)
+    specs = [planning.EventSpec(n_samples=len(c), n_emitters=1, snr=10.0, emitter0=e) for e, c in enumerate(clips)]
+    pl = planning.plan_batch(specs, C, Lir, sr, log2_block=lb)
+    batch = r.prepare(pl, clips, irs)
+    s_code, m_code = ct.c_int32(), ct.c_int32()
+    r.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(s_code), ct.byref(m_code))
+    res = batch.run()
+    res.check_finite()
+    print("asan run ok: block", B, "split", split, "accumulate code", s_code.value, float(np.abs(res.spatial_audio(1)).sum()))
+    for P_short in (3,):   # several workgroups per (event, bin tile) with few partitions: the one-unit LDS kernel
+        pl2 = planning.plan_batch(specs, C, P_short * B - 7, sr, log2_block=lb)
+        res2 = r.prepare(pl2, clips, irs[:, :, : P_short * B - 7]).run()
+        res2.check_finite()
+for C_enc, fmt in ((8, _hip.FRAMES_PCM16), (4, _hip.FRAMES_F32), (5, _hip.FRAMES_PCM16)):
+    T = 333
+    scene_in = r.mem.upload(rng.standard_normal(C_enc * T).astype(np.float32))
+    out = r.mem.zeros(C_enc * T, np.int16 if fmt == _hip.FRAMES_PCM16 else np.float32)
+    r.lib.call("al_encode_frames", r.mem.ptr(scene_in), C_enc, T, fmt, r.mem.ptr(out), r.mem.stream())
+print("asan run ok: round-2 kernels")

@@ -87,6 +87,12 @@ class TorchMemory:
     def ptr(self, buf) -> int:
         return buf.data_ptr()
 
+    def free_bytes(self) -> int:
+        """HBM not in use: free on the device plus what torch's caching allocator holds but has not handed out."""
+        free, _total = self.torch.cuda.mem_get_info(self.device)
+        cached = self.torch.cuda.memory_reserved(self.device) - self.torch.cuda.memory_allocated(self.device)
+        return int(free + cached)
+
     def download(self, buf) -> np.ndarray:
         """Device buffer -> fresh ndarray.  Large buffers land in page-locked memory from torch's caching host allocator
         (55 GB/s instead of 12 GB/s into freshly faulted pageable memory, profiles/r02_h2d_probe.txt); the array keeps
@@ -210,6 +216,23 @@ class Renderer:
                 host[off: off + len(src)] = src.host
         return host
 
+    def auto_chunk_events(self, plan: BatchPlan) -> Optional[int]:
+        """Events per chunk when the spectra workspace of the whole batch (H, X, Y: ``plan.workspace_bytes()``) would not fit
+        the budget -- ``AL_WORKSPACE_GB`` or 40 % of the HBM that is free right now -- else None (one chunk, the fast path:
+        chunking does not reduce time, profiles/r01_chunk_sweep.txt).  The chunks reuse ONE workspace, so a scene of any
+        number of events renders in bounded memory beside its inputs and outputs."""
+        budget = os.environ.get("AL_WORKSPACE_GB")
+        if budget is not None:
+            budget = float(budget) * 1e9
+        elif hasattr(self.mem, "free_bytes"):
+            budget = 0.4 * self.mem.free_bytes()
+        else:
+            return None
+        total, n = plan.workspace_bytes(), len(plan.events)
+        if total <= budget or n <= 1:
+            return None
+        return max(1, int(n * budget / total))
+
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                 chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
                 audio_dev=None) -> "PreparedBatch":
@@ -222,6 +245,8 @@ class Renderer:
         if ir_strides is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
             irs, ir_strides = self.upload_irs(irs)
         B = plan.block
+        if chunk_events is None:
+            chunk_events = self.auto_chunk_events(plan)
         chunks = plan.chunks(chunk_events)
         P, C = plan.n_partitions, plan.n_capsules
         h_blocks = max(max(c["n_emitters"] for c in chunks) * C * P, 1)

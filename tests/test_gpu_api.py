@@ -55,3 +55,4 @@ test_encode_frames_every_store_path = scenarios.test_encode_frames_every_store_p
 test_event_from_wav_file_resamples_on_the_device = scenarios.test_event_from_wav_file_resamples_on_the_device
 test_fx_match_the_reference_classes_outputs = scenarios.test_fx_match_the_reference_classes_outputs
 test_ambience_file_mode_matches_the_reference = scenarios.test_ambience_file_mode_matches_the_reference
+test_big_batches_chunk_themselves = scenarios.test_big_batches_chunk_themselves

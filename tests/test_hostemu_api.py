@@ -582,3 +582,29 @@ def test_ambience_file_mode_matches_the_reference(tmp_path):
     src = np.pad(src, ((0, 0), (0, max(0, n_src - src.shape[1]))))[:, :n_src]
     want = np.tile(src, (1, -(-5600 // n_src)))[:, :5600]
     assert got.shape == (2, 5600) and rel_rms(got, want) < 1e-5
+
+
+def test_big_batches_chunk_themselves(monkeypatch):
+    """A batch whose spectra workspace exceeds the budget (AL_WORKSPACE_GB, default 40 % of the free HBM) is rendered as
+    chunks of events over ONE reused workspace without the caller asking: same bits as the one-chunk render."""
+    from audiblelight_amd import plan as planning
+
+    r = syn.get_renderer()
+    rng = np.random.default_rng(31)
+    C, L, sr = 3, 2600, 8000
+    clips = [rng.standard_normal(n).astype(np.float32) for n in (5000, 3000, 7001, 4100, 6000, 2000)]
+    irs = (rng.standard_normal((C, len(clips), L)) * np.exp(-np.arange(L) / 400.0)).astype(np.float32)
+    specs = [planning.EventSpec(n_samples=len(c), n_emitters=1, snr=12.0, emitter0=i) for i, c in enumerate(clips)]
+    pl = planning.plan_batch(specs, C, L, sr, log2_block=10)
+    monkeypatch.delenv("AL_WORKSPACE_GB", raising=False)
+    whole = r.prepare(pl, clips, irs)
+    assert len(whole.descs) == 1
+    want = [whole.run().spatial_audio(i).copy() for i in range(len(clips))]
+    monkeypatch.setenv("AL_WORKSPACE_GB", str(pl.workspace_bytes() / 2.5 / 1e9))
+    assert r.auto_chunk_events(pl) == 2
+    chunked = r.prepare(pl, clips, irs)
+    assert len(chunked.descs) == 3 and [d.n_events for d in chunked.descs] == [2, 2, 2]
+    res = chunked.run()
+    res.check_finite()
+    for i in range(len(clips)):
+        np.testing.assert_array_equal(res.spatial_audio(i), want[i])

@@ -138,7 +138,7 @@ class BatchDriver:
             for off, src in device_clips:
                 audio_dev[off: off + len(src)] = src.device[: len(src)]
             release = [] if self.async_h2d else None
-            irs_dev, strides = r.upload_irs(job.irs, async_release=release)   # straight from the caller's memory
+            irs_dev, strides = r.upload_irs(job.irs, async_release=release, host_cast=False)   # straight from the caller's memory
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         self._slot_ready[st["slot"]] = ready

@@ -71,6 +71,41 @@ class TorchMemory:
         self._staging[1] = ev
         return dev
 
+    def upload_f64_as_f32(self, arr: np.ndarray, threads: Optional[int] = None):
+        """float64 host array -> float32 in HBM (what the reference's ``WorldState.get_irs()`` hands over is float64): converted
+        by a pool of threads (numpy releases the GIL while it casts) into a reused page-locked buffer, in chunks, each chunk
+        on its way by DMA while the next one converts.  Half the PCIe bytes of uploading the float64 tensor and converting on
+        the device: 22 ms instead of 28 ms for cfg2's 1.57 GB (profiles/r02_e2e_probe.txt)."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        flat = np.ascontiguousarray(arr).reshape(-1)
+        n = flat.size
+        threads = int(os.environ.get("AL_CONVERT_THREADS", threads or 8))
+        if not hasattr(self, "_convert"):
+            self._convert = dict(pool=None, threads=0, host=None, last=None)
+        cv = self._convert
+        if cv["pool"] is None or cv["threads"] != threads:
+            cv["pool"], cv["threads"] = ThreadPoolExecutor(threads), threads
+        if cv["last"] is not None:
+            cv["last"].synchronize()                 # the previous DMA out of the staging buffer must have finished
+        if cv["host"] is None or cv["host"].numel() < n:
+            cap = max(n, 0 if cv["host"] is None else cv["host"].numel() * 5 // 4)
+            cv["host"] = self.torch.empty((cap + 65535) // 65536 * 65536, dtype=self.torch.float32, pin_memory=True)
+        host = cv["host"][:n]
+        view = host.numpy()
+        dev = self.torch.empty(n, dtype=self.torch.float32, device=self.device)
+        n_chunks = max(1, min(8, n // (1 << 22)))
+        bounds = np.linspace(0, n, n_chunks + 1).astype(np.int64)
+        for a, b in zip(bounds[:-1], bounds[1:]):
+            cut = np.linspace(a, b, threads + 1).astype(np.int64)
+            list(cv["pool"].map(lambda i: np.copyto(view[cut[i]: cut[i + 1]], flat[cut[i]: cut[i + 1]], casting="same_kind"),
+                                range(threads)))
+            dev[a:b].copy_(host[a:b], non_blocking=True)
+        ev = self.torch.cuda.Event()
+        ev.record(self.torch.cuda.current_stream(self.device))
+        cv["last"] = ev
+        return dev
+
     def upload_async(self, arr: np.ndarray):
         """Large caller-owned array -> HBM by DMA without holding the calling thread: the array's pages are page-locked in
         place (hipHostRegister), the copy is enqueued on the current stream, and the returned ``release()`` must be
@@ -182,19 +217,31 @@ class Renderer:
         return self._twiddles[log2_block]
 
     # -- IR upload: (C, N, L) any float dtype -> float32 device tensor with 4-float aligned rows
-    def upload_irs(self, irs: np.ndarray, async_release: Optional[list] = None):
+    def upload_irs(self, irs: np.ndarray, async_release: Optional[list] = None, host_cast: Optional[bool] = None):
         """``async_release``: a list; when given and the memory provider can do it, the H2D copy is an asynchronous DMA
         from the caller's page-locked-in-place array and a ``release`` callable is appended (call it after the copy).
         The caller's (C, N, L) tensor goes to HBM AS IT IS (no host-side copy, cast or padding pass: the H2D copy of
         pageable memory runs at PCIe rate, a fresh ``np.zeros`` + copy at a fifth of it, profiles/r02_h2d_probe.txt);
-        float64 (what ``WorldState.get_irs()`` returns, worldstate.py:2183-2255) and rows whose length is not a
-        multiple of 4 are converted / re-pitched by a device kernel."""
+        rows whose length is not a multiple of 4 are re-pitched by a device kernel.  float64 (what ``WorldState.get_irs()``
+        returns, worldstate.py:2183-2255) is cast to float32 by a pool of host threads into page-locked memory, chunk by
+        chunk under the DMA of the previous chunk: 22 ms instead of 28 ms for cfg2's 1.57 GB (``host_cast=False`` /
+        ``AL_F64_UPLOAD=device``: upload the float64 bytes and cast on the device -- what the pipelined batch driver does,
+        whose upload thread gains nothing from the pool: profiles/r02_e2e_probe.txt)."""
         c, n, l = irs.shape
         lp = (l + 3) // 4 * 4
         if n == 0 or l == 0:
             return self.mem.zeros(max(c, 1) * lp), (lp, lp)
         if irs.dtype not in (np.float32, np.float64):
             irs = irs.astype(np.float32)
+        if host_cast is None:
+            host_cast = os.environ.get("AL_F64_UPLOAD", "host") == "host"
+        if irs.dtype == np.float64 and host_cast and hasattr(self.mem, "upload_f64_as_f32"):
+            raw = self.mem.upload_f64_as_f32(irs)        # converted on the host by a thread pool: half the PCIe bytes
+            if lp == l:
+                return raw, (n * lp, lp)
+            dev = self.mem.empty(c * n * lp)
+            self.lib.call("al_pack_irs_f32", self.mem.ptr(raw), self.mem.ptr(dev), c * n, l, lp, self.mem.stream())
+            return dev, (n * lp, lp)
         if async_release is not None and hasattr(self.mem, "upload_async"):
             raw, release = self.mem.upload_async(np.ascontiguousarray(irs).reshape(-1))
             async_release.append(release)

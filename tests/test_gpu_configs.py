@@ -164,11 +164,11 @@ def test_batch_driver_reports_writer_failures(gpu, tmp_path, monkeypatch):
     assert seen == ["s3", "s4"]                                  # what was handed over before the failure still came out
     drv, real, calls = batch.BatchDriver(gpu), gpu.upload_irs, []
 
-    def flaky(irs, async_release=None):
+    def flaky(irs, **kw):
         calls.append(1)
         if len(calls) == 2:
             raise MemoryError("upload failed")
-        return real(irs, async_release=async_release)
+        return real(irs, **kw)
 
     monkeypatch.setattr(gpu, "upload_irs", flaky)
     with pytest.raises(MemoryError, match="upload failed"):
@@ -293,3 +293,20 @@ def test_bench_collectives_on_rccl_with_one_rank():
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_per_rank"] == 4 * 4 * 240000
     assert out["data"] == "synthetic" and out["value"] > 0
+
+
+def test_float64_irs_host_cast_equals_device_cast(gpu, monkeypatch):
+    """What the reference's WorldState.get_irs() returns is float64: the thread-pool cast into page-locked memory (default
+    for synchronous renders) and the device-side cast (batch driver) put the same float32 bits into HBM, odd row lengths
+    included (re-pitched on the device either way)."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    for shape in ((3, 4, 20_001), (2, 3, 400_000)):
+        irs = rng.standard_normal(shape)
+        a, sa = gpu.upload_irs(irs, host_cast=True)
+        b, sb = gpu.upload_irs(irs, host_cast=False)
+        assert sa == sb and torch.equal(a, b)
+        pitch = sa[1]
+        got = gpu.mem.download(a)[: shape[0] * shape[1] * pitch].reshape(shape[0], shape[1], pitch)
+        np.testing.assert_array_equal(got[:, :, : shape[2]], irs.astype(np.float32))

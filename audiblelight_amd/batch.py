@@ -93,6 +93,9 @@ class BatchDriver:
         # 15.5 ms per cfg2 scene, profiles/r02_e2e_probe.txt)
         self.zero_copy_d2h = os.environ.get("AL_D2H", "dma") == "kernel"
         self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
+        # threads that cast float64 IR tensors to float32 in the planner stage (0: upload the float64 bytes, cast on the device)
+        self.cast_threads = int(os.environ.get("AL_CONVERT_THREADS", "8")) if os.environ.get("AL_F64_UPLOAD", "host") == "host" else 0
+        self._cast_pool = None
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
         """Reused page-locked host buffer of at least ``numel`` elements (a view of exactly ``numel``).  Page-locking costs
@@ -120,8 +123,25 @@ class BatchDriver:
             prev.synchronize()   # the slot's pinned clip buffer may still be the source of an H2D copy in flight
         audio_host = self._pinned_buffer("audio", torch.float32, pl.audio_floats, slot)
         r.pack_audio(pl, job.clips, out=audio_host.numpy())
-        return dict(job=job, plan=pl, mix=mix_plan, audio_host=audio_host, slot=slot, t0=time.perf_counter(),
-                    h2d=job.irs.nbytes + pl.audio_floats * 4)
+        st = dict(job=job, plan=pl, mix=mix_plan, audio_host=audio_host, slot=slot, t0=time.perf_counter(),
+                  h2d=job.irs.nbytes + pl.audio_floats * 4)
+        if job.irs.dtype == np.float64 and self.cast_threads > 0 and job.irs.size:
+            # float64 IRs (the reference's get_irs() dtype): cast HERE, in the planner thread's time, by a pool of threads into
+            # the slot's page-locked float32 buffer; the uploader then moves half the bytes, as one asynchronous DMA.  The cast
+            # (11 ms for cfg2) runs beside the upload of the previous scene (14 ms) instead of doubling it.
+            if self._cast_pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+
+                self._cast_pool = ThreadPoolExecutor(self.cast_threads)
+            flat = np.ascontiguousarray(job.irs).reshape(-1)
+            host = self._pinned_buffer("irs", torch.float32, flat.size, slot)
+            view = host.numpy()
+            cut = np.linspace(0, flat.size, self.cast_threads + 1).astype(np.int64)
+            list(self._cast_pool.map(lambda i: np.copyto(view[cut[i]: cut[i + 1]], flat[cut[i]: cut[i + 1]], casting="same_kind"),
+                                     range(self.cast_threads)))
+            st["irs_host_f32"] = host
+            st["h2d"] = flat.size * 4 + pl.audio_floats * 4
+        return st
 
     # -- stage 1b: H2D on the copy stream (PCIe-bound; the pageable IR copy holds the calling thread, not the GIL)
     def _upload(self, st, compute_stream=None):
@@ -138,7 +158,21 @@ class BatchDriver:
             for off, src in device_clips:
                 audio_dev[off: off + len(src)] = src.device[: len(src)]
             release = [] if self.async_h2d else None
-            irs_dev, strides = r.upload_irs(job.irs, async_release=release, host_cast=False)   # straight from the caller's memory
+            if "irs_host_f32" in st:                     # cast by the planner: one asynchronous DMA out of page-locked memory
+                c, n, l = job.irs.shape
+                lp = (l + 3) // 4 * 4
+                raw = st["irs_host_f32"].to(r.mem.device, non_blocking=True)
+                if lp == l:
+                    irs_dev, strides = raw, (n * lp, lp)
+                else:
+                    import ctypes as ct
+
+                    irs_dev, strides = r.mem.empty(c * n * lp), (n * lp, lp)
+                    r.lib.call("al_pack_irs_f32", r.mem.ptr(raw), r.mem.ptr(irs_dev), c * n, l, lp,
+                               ct.c_void_p(self.copy_stream.cuda_stream))
+                    raw.record_stream(self.copy_stream)
+            else:
+                irs_dev, strides = r.upload_irs(job.irs, async_release=release, host_cast=False)   # straight from the caller's memory
             ready = torch.cuda.Event()
             ready.record(self.copy_stream)
         self._slot_ready[st["slot"]] = ready

@@ -225,8 +225,8 @@ class Renderer:
         rows whose length is not a multiple of 4 are re-pitched by a device kernel.  float64 (what ``WorldState.get_irs()``
         returns, worldstate.py:2183-2255) is cast to float32 by a pool of host threads into page-locked memory, chunk by
         chunk under the DMA of the previous chunk: 22 ms instead of 28 ms for cfg2's 1.57 GB (``host_cast=False`` /
-        ``AL_F64_UPLOAD=device``: upload the float64 bytes and cast on the device -- what the pipelined batch driver does,
-        whose upload thread gains nothing from the pool: profiles/r02_e2e_probe.txt)."""
+        ``AL_F64_UPLOAD=device``: upload the float64 bytes and cast on the device; the pipelined batch driver casts in its
+        planner stage instead, beside the previous scene's upload: profiles/r02_e2e_probe.txt)."""
         c, n, l = irs.shape
         lp = (l + 3) // 4 * 4
         if n == 0 or l == 0:

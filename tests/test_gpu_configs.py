@@ -102,13 +102,14 @@ def oracle_scene(sc):
 def test_batch_driver_writes_what_the_oracle_mixes(gpu, tmp_path):
     """the pipelined multi-scene driver (H2D / render / device-side frame encoding / D2H / WAV writer)
     against the ORACLE's scenes: float32 frames within the parity tolerance, PCM_16 frames (soundfile's default subtype,
-    core.py:1840-1847) within one LSB of lrint(oracle * 32767); float64 IRs go through the device-side ingest kernel;
+    core.py:1840-1847) within one LSB of lrint(oracle * 32767); float64 IRs (cast in the planner stage, one with an odd row length) and float32 IRs;
     skip_existing leaves written scenes alone (benchmark.py:54-55)."""
     from scipy.io import wavfile
 
     from audiblelight_amd import batch, synthetic
 
     scenes = [synthetic.make_scene("cfg1", scene_index=i, scale=0.5) for i in range(4)]
+    scenes[3].irs = np.ascontiguousarray(scenes[3].irs[:, :, :-3])   # a row length that is not a multiple of 4 (float64 job below)
     jobs = [batch.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs.astype(np.float64) if i % 2 else sc.irs,
                            starts=sc.starts, ends=sc.ends, duration=sc.duration, sample_rate=sc.sr, name=f"s{i}")
             for i, sc in enumerate(scenes)]

@@ -427,10 +427,15 @@ def _ambience_on_device(r: engine.Renderer, ambience, shape):
     """(device noise, device scalar): load_ambience(normalize=True) x db_to_multiplier(ref_db, mean|noise|)."""
     dev = ambience.load_ambience_device(r) if hasattr(ambience, "load_ambience_device") else None
     if dev is None:
-        host = np.ascontiguousarray(ambience.load_ambience(normalize=True), dtype=np.float32)
+        host = np.asarray(ambience.load_ambience(normalize=True))
         if host.shape != tuple(shape):
             raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {host.shape}.")
-        dev = r.mem.upload(host.reshape(-1))
+        if host.dtype == np.float64 and hasattr(r.mem, "upload_f64_as_f32"):
+            # the reference's Ambience hands over float64 (737 MB at cfg2): cast by the thread pool under the DMA instead of a
+            # single-threaded astype (60 ms) in front of it
+            dev = r.mem.upload_f64_as_f32(host)
+        else:
+            dev = r.mem.upload(np.ascontiguousarray(host, dtype=np.float32).reshape(-1))
     elif tuple(ambience.device_shape) != tuple(shape):
         raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {tuple(ambience.device_shape)}.")
     n = shape[0] * shape[1]

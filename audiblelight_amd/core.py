@@ -63,6 +63,16 @@ class Event:
         return self.n_emitters
 
     @property
+    def filename(self) -> Optional[str]:
+        """Name of the audio file behind the event (event.py: ``filepath.name``): events sharing it share a DCASE source index."""
+        return self.metadata.get("filename") or (os.path.basename(self.filepath) if self.filepath else self.alias)
+
+    @property
+    def emitters_relative(self) -> dict:
+        """{mic: [[azimuth, elevation, distance], ...] per emitter} when the event came with positions (reference metadata)."""
+        return self.metadata.get("emitters_relative") or {}
+
+    @property
     def is_audio_loaded(self) -> bool:
         return self.audio is not None
 
@@ -331,12 +341,14 @@ class Scene:
         interleaved frames like ``soundfile.write(mic_audio.T, sr)`` (core.py:1840-1847) in soundfile's default WAV
         subtype ``PCM_16`` (``audio_subtype="FLOAT"`` keeps float32); frames are encoded on the device.
         ``metadata_json``: write ``<metadata_fname>.json`` (``to_dict``) when ``output_dir`` is given.
-        ``metadata_dcase`` / ``video`` belong to host-side subsystems that are out of scope here; asking
-        for them raises instead of silently skipping.
+        ``metadata_dcase``: write ``<metadata_fname>_<mic>.csv`` (``synthesize.generate_dcase2024_metadata``, host
+        bookkeeping; needs class indices and emitter positions in the events' metadata; off by default here because events
+        built from bare arrays carry neither).  ``video`` belongs to a host-side subsystem that is out of scope:
+        asking for it raises instead of silently skipping.
         """
-        if metadata_dcase or video:
-            raise NotImplementedError("DCASE metadata and video output are host-side features of the reference "
-                                      "(synthesize.py:742-878, core.py:1866) and are not part of this path")
+        if video:
+            raise NotImplementedError("video output is a host-side feature of the reference (core.py:1866) and is not "
+                                      "part of this path")
         import os
 
         if output_dir is not None:
@@ -355,4 +367,10 @@ class Scene:
                     wavfile.write(os.path.join(output_dir, f"{stem}_{mic}.wav"), self.sample_rate, frames)
         if metadata_json and output_dir is not None:
             self.to_json(os.path.join(output_dir, os.path.splitext(str(metadata_fname))[0] + ".json"))
+        if metadata_dcase and output_dir is not None:       # one CSV per microphone, no header (core.py:1864-1874)
+            from . import synthesize
+
+            stem = os.path.splitext(str(metadata_fname))[0]
+            for mic, df in synthesize.generate_dcase2024_metadata(self).items():
+                df.to_csv(os.path.join(output_dir, f"{stem}_{mic}.csv"), sep=",", encoding="utf-8", header=None)
         return self.audio

@@ -11,6 +11,7 @@ every TimeWarp call and the seed is stored with the vector.
 
     python tests/golden/make_fx_golden.py      ->  tests/golden/reference_fx_vectors.npz
 """
+import json
 import os
 import random
 import sys
@@ -83,6 +84,36 @@ def main():
         out[f"amb_raw_{j}"] = np.asarray(amb.load_ambience(ignore_cache=True, normalize=False)) if rows != 3 or channels == 3 else np.zeros(0)
         amb_cases.append(f"{rows},{channels},{duration},{seed}")
     out["amb_cases"] = np.array(amb_cases)
+    # G13: DCASE-2024 metadata rows (synthesize.py:742-878), the reference's own function on duck-typed events: static and
+    # moving events, two events sharing a file (same source index), two classes, an event clipped by the scene end
+    import types
+
+    import audiblelight.synthesize as ref_syn
+
+    def emitter(polar):
+        return types.SimpleNamespace(coordinates_relative_polar={m: np.array([p]) for m, p in polar.items()})
+
+    def dcase_event(alias, class_id, filename, start, end, polars):
+        return types.SimpleNamespace(alias=alias, class_id=class_id, filename=filename, scene_start=start, scene_end=end,
+                                     is_moving=len(polars) > 1, emitters=[emitter(p) for p in polars])
+
+    mics = ["mic000", "mic001"]
+    spec = [("e0", 3, "phone.wav", 0.5, 2.3, [[30.4, -10.6, 1.234]]),
+            ("e1", 3, "phone.wav", 4.0, 5.0, [[-120.0, 5.0, 2.5]]),
+            ("e2", 3, "other_phone.wav", 1.2, 3.7, [[10.0, 0.0, 1.0], [50.0, 20.0, 2.0], [90.0, 10.0, 1.5], [45.0, -5.0, 3.0]]),
+            ("e3", 7, "speech.wav", 8.6, 11.0, [[170.2, 44.5, 0.504]])]
+    events = []
+    for alias, cid, fname, t0, t1, polars in spec:
+        per_emitter = [{m: [az + 3.0 * k, el - 1.0 * k, d * (1 + 0.1 * k)] for k, m in enumerate(mics)} for az, el, d in polars]
+        events.append(dcase_event(alias, cid, fname, t0, t1, per_emitter))
+    scene_ns = types.SimpleNamespace(duration=10.0, state=types.SimpleNamespace(microphones={m: None for m in mics}),
+                                     get_events=lambda: events)
+    frames = ref_syn.generate_dcase2024_metadata(scene_ns)
+    for m in mics:
+        df = frames[m].reset_index()
+        out[f"dcase_{m}"] = df.to_numpy().astype(np.int64)
+    out["dcase_columns"] = np.array(list(frames[mics[0]].reset_index().columns))
+    out["dcase_spec"] = np.array(json.dumps(spec))
     path = os.path.join(HERE, "reference_fx_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, {k: getattr(v, "shape", None) for k, v in out.items() if k.startswith(("fade_0", "tw_0", "inv"))},

@@ -56,3 +56,4 @@ test_event_from_wav_file_resamples_on_the_device = scenarios.test_event_from_wav
 test_fx_match_the_reference_classes_outputs = scenarios.test_fx_match_the_reference_classes_outputs
 test_ambience_file_mode_matches_the_reference = scenarios.test_ambience_file_mode_matches_the_reference
 test_big_batches_chunk_themselves = scenarios.test_big_batches_chunk_themselves
+test_dcase_metadata_matches_the_reference_function = scenarios.test_dcase_metadata_matches_the_reference_function

@@ -331,8 +331,8 @@ def test_scene_generate_argument_list(golden, tmp_path):
     assert data.dtype == np.float32
     np.testing.assert_array_equal(data.T, out["mic000"])
     assert (tmp_path / "meta.json").exists()
-    with pytest.raises(NotImplementedError):
-        scene.generate(metadata_dcase=True)
+    with pytest.raises(ValueError, match="DCASE"):        # events built from bare arrays carry no class index / positions
+        scene.generate(output_dir=str(tmp_path), audio=False, metadata_dcase=True)
     with pytest.raises(NotImplementedError):
         scene.generate(video=True)
 
@@ -608,3 +608,41 @@ def test_big_batches_chunk_themselves(monkeypatch):
     res.check_finite()
     for i in range(len(clips)):
         np.testing.assert_array_equal(res.spatial_audio(i), want[i])
+
+
+def test_dcase_metadata_matches_the_reference_function(tmp_path):
+    """G13: generate_dcase2024_metadata (host bookkeeping, synthesize.py:742-878) against the rows the reference's own function
+    produced for the same events (two microphones, static and moving events, a shared audio file, two classes, an event clipped
+    by the scene end); then through Scene.generate(metadata_dcase=True) on the reference-format scene, one CSV per microphone."""
+    import json
+    import os
+    import types
+
+    import pandas as pd
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    z = np.load(os.path.join(here, "reference_fx_vectors.npz"))
+    spec = json.loads(str(z["dcase_spec"]))
+    mics = ["mic000", "mic001"]
+    events = []
+    for alias, cid, fname, t0, t1, polars in spec:
+        rel = {m: [[az + 3.0 * k, el - 1.0 * k, d * (1 + 0.1 * k)] for az, el, d in polars] for k, m in enumerate(mics)}
+        events.append(types.SimpleNamespace(alias=alias, class_id=cid, filename=fname, scene_start=t0, scene_end=t1,
+                                            is_moving=len(polars) > 1, emitters_relative=rel))
+    scene = types.SimpleNamespace(duration=10.0, state=types.SimpleNamespace(microphones={m: None for m in mics}),
+                                  events={e.alias: e for e in events})
+    got = syn.generate_dcase2024_metadata(scene)
+    for m in mics:
+        assert list(got[m].reset_index().columns) == list(z["dcase_columns"])
+        np.testing.assert_array_equal(got[m].reset_index().to_numpy().astype(np.int64), z[f"dcase_{m}"])
+    # the reference-format scene carries class indices and positions: CSVs next to the JSON
+    arrays = np.load(os.path.join(here, "reference_scene_arrays.npz"))
+    meta = json.load(open(os.path.join(here, "reference_scene.json")))
+    ref_scene = core.Scene.from_dict(meta, {a: arrays[f"clip_{a}"] for a in meta["events"]},
+                                     {m: arrays[f"irs_{m}"] for m in meta["state"]["microphones"]})
+    ref_scene.generate(output_dir=str(tmp_path), audio=False, metadata_dcase=True)
+    want = syn.generate_dcase2024_metadata(ref_scene)
+    for m in meta["state"]["microphones"]:
+        df = pd.read_csv(tmp_path / f"metadata_out_{m}.csv", header=None)
+        np.testing.assert_array_equal(df.to_numpy(), want[m].reset_index().to_numpy())
+        assert len(df) > 0 and set(df[1]) <= {e["class_id"] for e in meta["events"].values()}

@@ -455,7 +455,8 @@ def scene_jobs(scene, name: str, renderer: Optional[engine.Renderer] = None) -> 
 
 def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True, subtype: str = "PCM_16",
                    audio_fname: str = "audio_out", metadata_fname: str = "metadata_out", metadata_json: bool = True,
-                   driver: Optional[BatchDriver] = None, rank: int = 0, world_size: int = 1) -> BatchReport:
+                   driver: Optional[BatchDriver] = None, rank: int = 0, world_size: int = 1,
+                   metadata_dcase: bool = False) -> BatchReport:
     """The reference's dataset loops on the pipelined driver (scripts/generate/benchmark.py:35-82,
     scripts/generate/generate_with_random_events.py:222-238, scripts/seld/generate_dataset.py:96-260).
 
@@ -463,7 +464,9 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     scenes that are actually rendered).  Layout, as ``make_a_scene`` leaves it: ``<output_dir>/<name>/
     <audio_fname>_<mic>.wav`` ((T, C) frames, soundfile's default PCM_16 unless ``subtype="FLOAT"``) and
     ``<metadata_fname>.json`` = ``scene.to_dict()`` plus ``"time"`` (seconds from staging to the file on disk).
-    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55).
+    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55).  ``metadata_dcase``: also
+    ``<metadata_fname>_<mic>.csv`` per microphone (``synthesize.generate_dcase2024_metadata``; the events need class indices
+    and emitter positions in their metadata).
 
     ``rank`` / ``world_size``: one process per GPU, every process handed the SAME scene stream; process ``rank`` renders
     scenes ``rank, rank + world_size, ...`` of it (``distributed.shard_stream``) into the shared ``output_dir``.  Scenes
@@ -477,6 +480,7 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     driver = driver or BatchDriver(subtype=subtype)
     os.makedirs(output_dir, exist_ok=True)
     meta = {}
+    dcase = {}
     skipped = []
 
     def jobs():
@@ -491,6 +495,10 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
             per_mic = scene_jobs(scene, name, driver.r)
             # only the (small) metadata dictionary outlives the scene: a dataset run must not keep every clip alive
             meta[name] = (scene.to_dict() if hasattr(scene, "to_dict") else {}, [j.name for j in per_mic])
+            if metadata_dcase:   # rows are tiny; computed while the scene object is still alive
+                from . import synthesize
+
+                dcase[name] = synthesize.generate_dcase2024_metadata(scene)
             yield from per_mic
 
     def path_of(job):
@@ -499,6 +507,9 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
 
     rep = driver.run(jobs(), output_dir=output_dir, subtype=subtype, path_of=path_of)
     rep.skipped.extend(skipped)
+    for name, frames in dcase.items():
+        for mic, df in frames.items():
+            df.to_csv(os.path.join(output_dir, name, f"{metadata_fname}_{mic}.csv"), sep=",", encoding="utf-8", header=None)
     if metadata_json:
         for name, (d, job_names) in meta.items():
             d["time"] = max(rep.latencies.get(j, 0.0) for j in job_names)

@@ -311,3 +311,33 @@ def test_float64_irs_host_cast_equals_device_cast(gpu, monkeypatch):
         pitch = sa[1]
         got = gpu.mem.download(a)[: shape[0] * shape[1] * pitch].reshape(shape[0], shape[1], pitch)
         np.testing.assert_array_equal(got[:, :, : shape[2]], irs.astype(np.float32))
+
+
+def test_render_dataset_writes_dcase_csvs(gpu, tmp_path):
+    """The dataset loop with metadata_dcase=True on the reference-format scene (class indices + emitter positions in its
+    metadata): audio, JSON and one DCASE-2024 CSV per microphone in the scene's folder."""
+    import json
+
+    import pandas as pd
+
+    from audiblelight_amd import batch, core, synthesize as syn
+
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    arrays = np.load(os.path.join(here, "reference_scene_arrays.npz"))
+    meta = json.load(open(os.path.join(here, "reference_scene.json")))
+
+    def scene():
+        return core.Scene.from_dict(meta, {a: arrays[f"clip_{a}"] for a in meta["events"]},
+                                    {m: arrays[f"irs_{m}"] for m in meta["state"]["microphones"]})
+
+    syn.set_renderer(gpu)
+    try:
+        rep = batch.render_dataset([("ref", scene)], str(tmp_path), metadata_dcase=True, subtype="FLOAT")
+        assert rep.n_scenes == len(meta["state"]["microphones"])
+        want = syn.generate_dcase2024_metadata(scene())
+        for mic in meta["state"]["microphones"]:
+            assert (tmp_path / "ref" / f"audio_out_{mic}.wav").exists() and (tmp_path / "ref" / "metadata_out.json").exists()
+            df = pd.read_csv(tmp_path / "ref" / f"metadata_out_{mic}.csv", header=None)
+            np.testing.assert_array_equal(df.to_numpy(), want[mic].reset_index().to_numpy())
+    finally:
+        syn.set_renderer(None)

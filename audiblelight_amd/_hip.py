@@ -15,6 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
+ABI_VERSION = 3   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
 FLAG_FUSED_STATIC = 2
@@ -36,8 +37,18 @@ STREAM_DTYPE = np.dtype([
 assert EVENT_DTYPE.itemsize == 56 and STREAM_DTYPE.itemsize == 32
 
 
-class AlBatch(ct.Structure):
+class _Versioned(ct.Structure):
+    """Descriptor with ``struct_size`` / ``abi_version`` at its head, filled in here so that the library can refuse a
+    descriptor laid out for another header version instead of misreading it."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.struct_size, self.abi_version = ct.sizeof(type(self)), ABI_VERSION
+
+
+class AlBatch(_Versioned):
     _fields_ = [
+        ("struct_size", ct.c_int32), ("abi_version", ct.c_int32),
         ("log2_block", ct.c_int32), ("n_capsules", ct.c_int32), ("n_events", ct.c_int32), ("n_streams", ct.c_int32),
         ("n_emitters", ct.c_int32), ("ir_len", ct.c_int32), ("ir_stride_c", ct.c_int64), ("ir_stride_n", ct.c_int64),
         ("n_partitions", ct.c_int32), ("max_blocks", ct.c_int32), ("max_nj", ct.c_int32), ("hop", ct.c_int32),
@@ -52,8 +63,9 @@ class AlBatch(ct.Structure):
     ]
 
 
-class AlMix(ct.Structure):
+class AlMix(_Versioned):
     _fields_ = [
+        ("struct_size", ct.c_int32), ("abi_version", ct.c_int32),
         ("n_capsules", ct.c_int32), ("n_samples", ct.c_int32), ("tile", ct.c_int32), ("n_tiles", ct.c_int32),
         ("accumulate", ct.c_int32), ("reserved", ct.c_int32),
         ("tile_ptr", ct.c_void_p), ("tile_events", ct.c_void_p), ("slot_src", ct.c_void_p), ("slot_len", ct.c_void_p),
@@ -138,6 +150,10 @@ class Library:
             fn = getattr(self._dll, name)  # AttributeError if the library does not export it
             fn.restype, fn.argtypes = res, args
             setattr(self, "_" + name, fn)
+        built = self._al_abi_version()
+        if built != ABI_VERSION:
+            raise RuntimeError(f"audiblelight_amd: {path} implements C-ABI version {built}, this package binds version "
+                               f"{ABI_VERSION}: rebuild it (python -c 'import __graft_entry__ as g; g.build()')")
 
     def last_error(self) -> str:
         return (self._al_last_error() or b"").decode()

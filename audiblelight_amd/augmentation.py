@@ -51,12 +51,16 @@ def _positive(x, cast=float):
 
 class DeviceClip:
     """A mono clip resident in HBM plus its length; FX ping-pong between two buffers.  A whole FX chain and the peak
-    normalisation run on ONE DeviceClip: one upload, N kernel launches, at most one download."""
+    normalisation run on ONE DeviceClip: one upload, N kernel launches, at most one download.  ``device``: the samples are
+    already in HBM (a view of the scene's staging arena, ``stage_clips``): nothing is uploaded here."""
 
-    def __init__(self, renderer, host: np.ndarray):
+    def __init__(self, renderer, host: Optional[np.ndarray] = None, device=None, n: Optional[int] = None):
         self.r = renderer
-        self.n = int(host.shape[-1])
-        self.buf = renderer.mem.upload(np.ascontiguousarray(host, dtype=np.float32))
+        if device is not None:
+            self.n, self.buf = int(n), device
+        else:
+            self.n = int(host.shape[-1])
+            self.buf = renderer.mem.upload(np.ascontiguousarray(host, dtype=np.float32))
         self.alt = None
         self.uploads, self.downloads = 1, 0   # PCIe crossings of the samples (tests assert the chain stays in HBM)
 
@@ -71,9 +75,18 @@ class DeviceClip:
         if n is not None:
             self.n = n
 
-    def host(self) -> np.ndarray:
+    def host(self, normalize: bool = False) -> np.ndarray:
+        """The clip on the host; ``normalize``: peak-normalised (event.py:535-536) in a device COPY, so the resident clip
+        stays as the chain left it (the renderer folds the same scalar into the clip spectra instead, ``al_clip_scales``)."""
         self.downloads += 1
-        return self.r.mem.download(self.buf)[: self.n].astype(np.float32)
+        if not normalize:
+            return self.r.mem.download(self.buf)[: self.n].astype(np.float32)
+        r, dst = self.r, self.other()
+        dst[: self.n] = self.buf[: self.n]
+        scale = r.mem.empty(1)
+        r.lib.call("al_peak_scale", r.mem.ptr(dst), self.n, ct.c_float(1.0), r.mem.ptr(scale), r.mem.stream())
+        r.lib.call("al_scale_rows", r.mem.ptr(dst), self.n, r.mem.ptr(scale), r.mem.stream())
+        return r.mem.download(dst)[: self.n].astype(np.float32)
 
     def peak_normalize(self) -> None:
         """``a / max(|a| + tiny(a))`` (event.py:535-536): the peak is reduced into a DEVICE scalar and applied from it
@@ -82,6 +95,27 @@ class DeviceClip:
         scale = r.mem.empty(1)
         r.lib.call("al_peak_scale", r.mem.ptr(self.buf), self.n, ct.c_float(1.0), r.mem.ptr(scale), r.mem.stream())
         r.lib.call("al_scale_rows", r.mem.ptr(self.buf), self.n, r.mem.ptr(scale), r.mem.stream())
+
+
+def stage_clips(renderer, raws) -> list:
+    """Raw clips of one scene -> HBM through ONE page-locked arena and ONE asynchronous DMA (instead of a blocking pageable
+    copy per event); returns one DeviceClip per clip, each a 4-float aligned view of the arena."""
+    mem = renderer.mem
+    if not raws:
+        return []
+    if not hasattr(mem, "upload_staged"):
+        return [DeviceClip(renderer, raw) for raw in raws]
+    offs, total = [], 0
+    for raw in raws:
+        offs.append(total)
+        total += (len(raw) + 3) // 4 * 4
+
+    def fill(view):
+        for off, raw in zip(offs, raws):
+            view[off: off + len(raw)] = raw
+
+    arena = mem.upload_staged(total, fill)
+    return [DeviceClip(renderer, device=arena[off: off + (len(raw) + 3) // 4 * 4], n=len(raw)) for off, raw in zip(offs, raws)]
 
 
 def _fx(clip: DeviceClip, op: int, p0: float = 0.0, iparams=None, out_of_place: bool = False) -> None:

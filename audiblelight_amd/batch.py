@@ -251,14 +251,17 @@ class BatchDriver:
     def run(self, jobs: Iterable[SceneJob], output_dir: Optional[str] = None,
             on_scene: Optional[Callable[[str, np.ndarray], None]] = None, check_finite: bool = True,
             subtype: Optional[str] = None, skip_existing: bool = False,
-            path_of: Optional[Callable[[SceneJob], str]] = None, copy_for_callback: bool = True) -> BatchReport:
+            path_of: Optional[Callable[[SceneJob], str]] = None, copy_for_callback: bool = True,
+            after_write: Optional[Callable[[SceneJob, float], None]] = None) -> BatchReport:
         """Render all jobs.  With ``output_dir`` every scene is written to ``<output_dir>/<name>.wav`` (or
         ``path_of(job)``): (T, C) interleaved frames like ``soundfile.write(audio.T, sr)`` (core.py:1840-1847), subtype
         ``PCM_16`` (soundfile's default for WAV) or ``FLOAT``; ``skip_existing`` leaves scenes whose file exists alone
         (scripts/generate/benchmark.py:54-55).  ``on_scene(name, array)`` receives a (C, T) float32 array of its own
-        (a copy: the page-locked download buffers are reused a few scenes later (``depth + 2`` + writer threads); ``copy_for_callback=False``
-        hands out the view instead, for callbacks that consume it before returning).  A failure in the writer thread
-        (non-finite audio, disk error, callback error) stops the run and is re-raised here."""
+        (a copy: the page-locked download buffers go back to a free list when the writer is done with them and are reused by
+        later scenes; ``copy_for_callback=False`` hands out the view instead, for callbacks that consume it before returning).
+        ``after_write(job, latency_s)`` runs in the writer thread once the job's file is on disk / its callback has returned
+        (``render_dataset`` writes a scene's metadata from it).  A failure in the writer thread (non-finite audio, disk
+        error, callback error) stops the run and is re-raised here."""
         subtype = subtype or self.subtype
         if subtype not in SUBTYPES:
             raise ValueError(f"subtype must be one of {sorted(SUBTYPES)}")
@@ -272,6 +275,12 @@ class BatchDriver:
             path_of = lambda job: os.path.join(output_dir, f"{job.name}.wav")  # noqa: E731
 
         def write_one(st):
+            try:
+                write_one_locked_buffers(st)
+            finally:
+                free_out.put(st["out_slot"])   # only now may a later scene's D2H copy land in this page-locked buffer
+
+        def write_one_locked_buffers(st):
             st["landed"].synchronize()
             for release in st.get("release", ()):   # the scene is out, so its H2D copy is long done: unpin the caller's IRs
                 release()
@@ -293,8 +302,11 @@ class BatchDriver:
                     on_scene(st["job"].name, view.copy() if copy_for_callback else view)
                 with book:
                     rep.d2h_bytes += c * t * 4
+            latency = time.perf_counter() - st["t0"]
             with book:
-                rep.latencies[st["job"].name] = time.perf_counter() - st["t0"]
+                rep.latencies[st["job"].name] = latency
+            if after_write is not None:
+                after_write(st["job"], latency)
 
         def writer():
             while True:
@@ -302,6 +314,7 @@ class BatchDriver:
                 if item is None:
                     return
                 if failure:
+                    free_out.put(item["out_slot"])
                     continue          # keep draining so the producer never blocks on a full queue
                 try:
                     write_one(item)
@@ -314,9 +327,14 @@ class BatchDriver:
         for th in threads:
             th.start()
         t0 = time.perf_counter()
-        # page-locked output buffers live at once: being rendered, `depth` + 1 queued for the writers, one per writer thread
-        # (back-pressure of the bounded queue guarantees it); clip staging buffers are guarded by their H2D event
+        # Page-locked output buffers are handed out from a FREE LIST and come back when the writer thread that holds one has
+        # finished with it (writers complete out of order: a count bound alone does not say WHICH buffers are still being
+        # read by a slow `wavfile.write`).  Enough for: one being rendered, `depth` + 1 queued, one per writer thread.
+        # Clip staging buffers are guarded by their H2D event.
         out_slots, in_slots = self.depth + 2 + len(threads), 4
+        free_out: "queue.Queue" = queue.Queue()
+        for slot in range(out_slots):
+            free_out.put(slot)
         compute = self.torch.cuda.current_stream(self.r.mem.device)
         planned: "queue.Queue" = queue.Queue(maxsize=1)
         uploaded: "queue.Queue" = queue.Queue(maxsize=1)
@@ -348,7 +366,7 @@ class BatchDriver:
                         continue
                     ta = time.perf_counter()
                     st = self._plan(job, index % in_slots)
-                    st.update(index=index, out_slot=index % out_slots)
+                    st.update(index=index)
                     index += 1
                     spend("plan", time.perf_counter() - ta)
                     if not hand_over(planned, st):
@@ -393,6 +411,14 @@ class BatchDriver:
                 if cur is None:
                     break
                 tb = time.perf_counter()
+                cur["out_slot"] = None
+                while cur["out_slot"] is None and not failure:   # a free page-locked output buffer (back-pressure on slow writers)
+                    try:
+                        cur["out_slot"] = free_out.get(timeout=0.05)
+                    except queue.Empty:
+                        pass
+                if cur["out_slot"] is None:
+                    break
                 st = self._download(self._render(cur), want_frames, want_scene, subtype)   # enqueue only (asynchronous)
                 tc = time.perf_counter()
                 rep.n_scenes += 1
@@ -464,7 +490,9 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     scenes that are actually rendered).  Layout, as ``make_a_scene`` leaves it: ``<output_dir>/<name>/
     <audio_fname>_<mic>.wav`` ((T, C) frames, soundfile's default PCM_16 unless ``subtype="FLOAT"``) and
     ``<metadata_fname>.json`` = ``scene.to_dict()`` plus ``"time"`` (seconds from staging to the file on disk).
-    ``skip_existing``: a scene whose folder exists is left alone (benchmark.py:54-55).  ``metadata_dcase``: also
+    ``skip_existing``: a scene whose folder holds its metadata file (written last, from the writer path, as soon as the
+    scene's last microphone is on disk) is left alone (benchmark.py:54-55); a folder an interrupted run left without it is
+    rendered again.  ``metadata_dcase``: also
     ``<metadata_fname>_<mic>.csv`` per microphone (``synthesize.generate_dcase2024_metadata``; the events need class indices
     and emitter positions in their metadata).
 
@@ -480,41 +508,73 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     driver = driver or BatchDriver(subtype=subtype)
     os.makedirs(output_dir, exist_ok=True)
     meta = {}
-    dcase = {}
+    meta_lock = threading.Lock()
     skipped = []
+
+    def finish_scene(name):
+        """Metadata of one scene, written from the writer path the moment its last microphone is on disk (the reference
+        writes it per scene inside make_a_scene): an interrupted run leaves complete scenes complete, and the JSON is the
+        completion marker ``skip_existing`` looks for."""
+        with meta_lock:
+            d, latency, frames = meta[name]["dict"], meta[name]["latency"], meta[name]["dcase"]
+            meta[name] = None        # only the small bookkeeping above outlives the scene: drop it too
+        for mic, df in (frames or {}).items():
+            df.to_csv(os.path.join(output_dir, name, f"{metadata_fname}_{mic}.csv"), sep=",", encoding="utf-8", header=None)
+        if not metadata_json:
+            return
+        d["time"] = latency
+        tmp = os.path.join(output_dir, name, f".{metadata_fname}.json.tmp")
+        with open(tmp, "w") as fh:
+            json.dump(d, fh, indent=4, ensure_ascii=False)
+        os.replace(tmp, os.path.join(output_dir, name, f"{metadata_fname}.json"))
+
+    def after_write(job, latency):
+        name = job.name.rsplit("/", 1)[0]
+        with meta_lock:
+            entry = meta[name]
+            entry["left"] -= 1
+            entry["latency"] = max(entry["latency"], latency)
+            last = entry["left"] == 0
+        if last:
+            finish_scene(name)
+
+    def complete(folder):
+        """A scene folder counts as done when its metadata file exists (written last); without ``metadata_json`` any
+        existing folder does, as in the reference (benchmark.py:54-55)."""
+        if not os.path.isdir(folder):
+            return False
+        return os.path.exists(os.path.join(folder, f"{metadata_fname}.json")) if metadata_json else True
 
     def jobs():
         for name, scene in scenes:
             folder = os.path.join(output_dir, name)
-            if skip_existing and os.path.isdir(folder):
+            if skip_existing and complete(folder):
                 skipped.append(name)
                 continue
             if callable(scene) and not hasattr(scene, "events"):
                 scene = scene()
             os.makedirs(folder, exist_ok=True)
             per_mic = scene_jobs(scene, name, driver.r)
-            # only the (small) metadata dictionary outlives the scene: a dataset run must not keep every clip alive
-            meta[name] = (scene.to_dict() if hasattr(scene, "to_dict") else {}, [j.name for j in per_mic])
+            frames = None
             if metadata_dcase:   # rows are tiny; computed while the scene object is still alive
                 from . import synthesize
 
-                dcase[name] = synthesize.generate_dcase2024_metadata(scene)
+                frames = synthesize.generate_dcase2024_metadata(scene)
+            # only the (small) metadata dictionary outlives the scene: a dataset run must not keep every clip alive
+            with meta_lock:
+                meta[name] = dict(dict=scene.to_dict() if hasattr(scene, "to_dict") else {}, left=len(per_mic), latency=0.0,
+                                  dcase=frames)
+            if not per_mic:          # a scene without microphones has nothing to render: its metadata is all there is
+                finish_scene(name)
             yield from per_mic
 
     def path_of(job):
         name, mic = job.name.rsplit("/", 1)
         return os.path.join(output_dir, name, f"{audio_fname}_{mic}.wav")
 
-    rep = driver.run(jobs(), output_dir=output_dir, subtype=subtype, path_of=path_of)
+    rep = driver.run(jobs(), output_dir=output_dir, subtype=subtype, path_of=path_of,
+                     after_write=after_write if (metadata_json or metadata_dcase) else None)
     rep.skipped.extend(skipped)
-    for name, frames in dcase.items():
-        for mic, df in frames.items():
-            df.to_csv(os.path.join(output_dir, name, f"{metadata_fname}_{mic}.csv"), sep=",", encoding="utf-8", header=None)
-    if metadata_json:
-        for name, (d, job_names) in meta.items():
-            d["time"] = max(rep.latencies.get(j, 0.0) for j in job_names)
-            with open(os.path.join(output_dir, name, f"{metadata_fname}.json"), "w") as fh:
-                json.dump(d, fh, indent=4, ensure_ascii=False)
     return rep
 
 

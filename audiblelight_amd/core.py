@@ -93,14 +93,15 @@ class Event:
         self._spatial_audio_dry = OrderedDict()
         self._spatial_audio_dry_padded = OrderedDict()
 
-    def _device_chain(self, normalize: bool):
-        """Raw clip -> HBM once, the whole FX chain and the peak normalisation there (augmentation.run_chain)."""
+    def _device_chain(self, normalize: bool, staged=None):
+        """Raw clip -> HBM once, the whole FX chain (and, if asked, the peak normalisation) there (augmentation.run_chain).
+        ``staged``: a DeviceClip already holding the raw clip (the scene's one-DMA staging arena, ``stage_event_chains``)."""
         from . import augmentation, synthesize
 
         from . import ingest
 
         device_fx = all(hasattr(a, "process_device") for a in self.augmentations)
-        clip = augmentation.DeviceClip(synthesize.get_renderer(), self._raw)
+        clip = staged if staged is not None else augmentation.DeviceClip(synthesize.get_renderer(), self._raw)
         ingest.resample_clip(clip, self.native_sample_rate, self.sample_rate)
         if not device_fx:   # foreign callables (e.g. host pedalboard FX of the reference): run them where they live
             out = clip.host() if self.native_sample_rate != self.sample_rate else self._raw.copy()
@@ -109,6 +110,22 @@ class Event:
             clip = augmentation.DeviceClip(synthesize.get_renderer(), out)
             return augmentation.run_chain(clip, [], normalize)
         return augmentation.run_chain(clip, self.augmentations, normalize)
+
+    def _foldable(self) -> bool:
+        from . import augmentation
+
+        return self.native_sample_rate == self.sample_rate and augmentation.fold_scalars(self.augmentations) is not None
+
+    def _chain(self, ignore_cache: bool, staged=None):
+        """The clip behind the FX chain, NOT yet peak-normalised, resident in HBM; ONE realisation per event, kept until
+        ``clear_audio`` (the reference's ``load_audio`` caches ``self.audio`` the same way, event.py:507-510,538): every
+        microphone, the dry path and ``load_audio`` see the same TimeWarp* coin flips, and a deterministic chain is
+        uploaded and run once, not once per microphone."""
+        clip = None if ignore_cache else getattr(self, "_last_chain", None)
+        if clip is None:
+            clip = self._device_chain(False, staged)
+            self._last_chain = clip
+        return clip
 
     @classmethod
     def from_file(cls, filepath: str, alias: str, sample_rate: int, event_start: float = 0.0,
@@ -127,28 +144,27 @@ class Event:
         One upload, the chain on the device, one download (no intermediate copies between FX)."""
         if self.is_audio_loaded and not ignore_cache:
             return self.audio
-        clip = self._device_chain(bool(normalize))
-        out = clip.host()
+        out = self._chain(bool(ignore_cache)).host(normalize=bool(normalize))
         valid_audio(out)
         self.audio = out
-        self._last_chain = clip
         return self.audio
 
-    def clip_source(self, ignore_cache: Optional[bool] = False):
+    def clip_source(self, ignore_cache: Optional[bool] = False, chain_is_fresh: bool = False):
         """What the renderer needs of this event's clip WITHOUT bringing samples back to the host
         (engine.ClipSource): a chain of pure scalars (Gain, Invert) + peak normalisation becomes the raw clip plus
-        one device-evaluated scalar; any other chain runs on the device and is handed over in HBM; a clip somebody
-        already loaded to the host (``self.audio``) is used as it is."""
+        one device-evaluated scalar; any other chain runs on the device ONCE per event (``_chain``) and is handed over in
+        HBM with its peak normalisation left to the same device scalar (``al_clip_scales``: no extra pass over the clip);
+        a clip somebody already loaded to the host (``self.audio``) is used as it is.  ``chain_is_fresh``: the cached chain
+        was run for THIS render (``stage_event_chains``), so it is used even when ``ignore_cache`` asks for a new one."""
         from . import augmentation, engine
 
         if self.is_audio_loaded and not ignore_cache:
             return engine.ClipSource(host=np.ascontiguousarray(self.audio, dtype=np.float32), n=len(self.audio))
-        folded = augmentation.fold_scalars(self.augmentations) if self.native_sample_rate == self.sample_rate else None
-        if folded is not None:
-            return engine.ClipSource(host=self._raw, n=len(self._raw), prescale=folded, normalize=True)
-        clip = self._device_chain(True)
-        self._last_chain = clip
-        return engine.ClipSource(device=clip.buf, n=clip.n)
+        if self._foldable():
+            return engine.ClipSource(host=self._raw, n=len(self._raw), prescale=augmentation.fold_scalars(self.augmentations),
+                                     normalize=True)
+        clip = self._chain(bool(ignore_cache) and not chain_is_fresh)
+        return engine.ClipSource(device=clip.buf, n=clip.n, prescale=1.0, normalize=True)
 
     def to_dict(self) -> dict:
         """The reference's Event metadata layout (event.py:568-620).  Keys this path does not compute (emitter
@@ -195,6 +211,24 @@ class Event:
                    direct_path_time_ms=d.get("direct_path_time_ms"), class_label=d.get("class_label"),
                    class_id=d.get("class_id"), filepath=d.get("filepath"), event_start=d.get("event_start") or 0.0,
                    duration=d["duration"], metadata=keep)
+
+
+def stage_event_chains(events, ignore_cache: bool = False) -> list:
+    """Before a scene is rendered: the raw clips of every event whose FX chain has to RUN on the device (not foldable into a
+    scalar, no cached realisation, nothing loaded to the host) go to HBM through one page-locked arena and one asynchronous
+    DMA, and their chains run there (event.py:520-539 does a blocking load + host chain per event)."""
+    from . import augmentation, synthesize
+
+    todo = [ev for ev in events
+            if isinstance(ev, Event) and not (ev.is_audio_loaded and not ignore_cache) and not ev._foldable()
+            and (ignore_cache or getattr(ev, "_last_chain", None) is None)
+            and all(hasattr(a, "process_device") for a in ev.augmentations)]
+    if not todo:
+        return []
+    staged = augmentation.stage_clips(synthesize.get_renderer(), [ev._raw for ev in todo])
+    for ev, clip in zip(todo, staged):
+        ev._chain(True, staged=clip)
+    return todo
 
 
 class MicArray:
@@ -332,7 +366,7 @@ class Scene:
         with open(path) as fh:
             return cls.from_dict(json.load(fh), clips, irs)
 
-    def generate(self, output_dir=None, audio: bool = True, metadata_json: bool = True, metadata_dcase: bool = False,
+    def generate(self, output_dir=None, audio: bool = True, metadata_json: bool = True, metadata_dcase: bool = True,
                  audio_fname: str = "audio_out", metadata_fname: str = "metadata_out", video: bool = False,
                  video_fname: str = "video_out", audio_subtype: str = "PCM_16") -> Dict[str, np.ndarray]:
         """Render every event and mix the scene, with the reference's argument list (core.py:1789-1874).
@@ -342,9 +376,10 @@ class Scene:
         subtype ``PCM_16`` (``audio_subtype="FLOAT"`` keeps float32); frames are encoded on the device.
         ``metadata_json``: write ``<metadata_fname>.json`` (``to_dict``) when ``output_dir`` is given.
         ``metadata_dcase``: write ``<metadata_fname>_<mic>.csv`` (``synthesize.generate_dcase2024_metadata``, host
-        bookkeeping; needs class indices and emitter positions in the events' metadata; off by default here because events
-        built from bare arrays carry neither).  ``video`` belongs to a host-side subsystem that is out of scope:
-        asking for it raises instead of silently skipping.
+        bookkeeping; on by default like the reference, core.py:1794; it needs class indices and emitter positions in the
+        events' metadata and raises the reference's error without them: pass ``metadata_dcase=False`` for events built from
+        bare arrays).  ``video`` belongs to a host-side subsystem that is out of scope: asking for it raises
+        instead of silently skipping.
         """
         if video:
             raise NotImplementedError("video output is a host-side feature of the reference (core.py:1866) and is not "

@@ -892,6 +892,17 @@ __global__ __launch_bounds__(256) void k_resample_poly(const float *__restrict__
   }
 }
 
+// float -> PCM_16 as python-soundfile writes it: it enables SFC_SET_CLIPPING on every file it opens, so libsndfile converts
+// with f2s_clip_array: scaled = x * 0x8000 (float); >= 0x7FFF -> 0x7FFF, <= -0x8000 -> -0x8000, else lrintf(scaled)
+// (round half to even).  (Without clipping libsndfile scales by 0x7FFF instead; round 2 encoded that.)  soundfile is not in
+// the build container, so this follows libsndfile's source, not a golden file: parity unpinned by definition.
+__device__ __forceinline__ int16_t pcm16_of(float x) {
+  const float scaled = x * 32768.0f;
+  if (scaled >= 32767.0f) return (int16_t)32767;
+  if (scaled <= -32768.0f) return (int16_t)-32768;
+  return (int16_t)rintf(scaled);   // NaN never reaches here: non-finite scenes are refused before encoding
+}
+
 // (C, T) float32 scene -> (T, C) interleaved frames, the layout soundfile.write(audio.T) puts on disk (core.py:1840-1847).
 // One workgroup per tile of 32 capsules x 64 samples through LDS: reads run along t, writes along c.
 template <bool PCM16>
@@ -915,7 +926,7 @@ __global__ __launch_bounds__(256) void k_encode_frames(const float *__restrict__
     if (t < n_samples && c0 + cg < n_capsules) {
       int16_t q[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) q[i] = (int16_t)fmin(fmax(rint((double)tile[cg + i][tl] * 32767.0), -32768.0), 32767.0);
+      for (int i = 0; i < 8; ++i) q[i] = pcm16_of(tile[cg + i][tl]);
       struct alignas(16) Frames8 { uint32_t w[4]; } v;
 #pragma unroll
       for (int i = 0; i < 4; ++i) v.w[i] = (uint32_t)(uint16_t)q[2 * i] | ((uint32_t)(uint16_t)q[2 * i + 1] << 16);
@@ -942,9 +953,7 @@ __global__ __launch_bounds__(256) void k_encode_frames(const float *__restrict__
     if (c < n_capsules && t < n_samples) {
       const float x = tile[cl][tt + tl];
       if (PCM16) {
-        // libsndfile float -> short with its default normalisation: lrint(x * 0x7FFF); saturated here (it would wrap)
-        const double q = rint((double)x * 32767.0);
-        reinterpret_cast<int16_t *>(out)[t * n_capsules + c] = (int16_t)fmin(fmax(q, -32768.0), 32767.0);
+        reinterpret_cast<int16_t *>(out)[t * n_capsules + c] = pcm16_of(x);
       } else {
         reinterpret_cast<float *>(out)[t * n_capsules + c] = x;
       }
@@ -979,6 +988,8 @@ int check_launch(const char *what) { return check_error(hipGetLastError(), what)
 
 int check_batch(const al_batch *b) {
   if (!b) return fail(AL_E_BADARG, "null batch");
+  if (b->struct_size != (int32_t)sizeof(al_batch) || b->abi_version != AL_ABI_VERSION)
+    return fail(AL_E_BADARG, "al_batch was built against another version of audiblelight_hip.h (struct_size / abi_version)");
   if (b->log2_block < AL_MIN_LOG2_BLOCK || b->log2_block > AL_MAX_LOG2_BLOCK)
     return fail(AL_E_UNSUPPORTED, "log2_block must be in [10, 14]");
   if (b->n_capsules <= 0 || b->n_events < 0 || b->n_streams < 0) return fail(AL_E_BADARG, "bad batch sizes");
@@ -992,10 +1003,95 @@ int check_batch(const al_batch *b) {
 
 }  // namespace
 
+// ONE description of what al_spectral_mac launches for a batch: al_spectral_mac launches from it, al_spectral_mac_variant
+// reports it, so the parity tests' "which instantiation ran" assertion cannot drift from the launcher.
+// Codes: tile kernel k_spectral_mac<KT,PT,VB,KSPLIT> = 1000000*KSPLIT + 10000*KT + 100*PT + VB; capsule-loop kernels
+// 3120000 + 100*P + {1: k_spectral_mac_static<12,P,1>, 2: <12,P,2>, 3: k_spectral_mac_static_lds (P <= 12: <12,P,1>,
+// 13..16: <12,ceil(P/2),2>)}; sliding-window kernel k_spectral_mac_moving<6,PT,1> = 600 + PT.
+namespace {
+enum MacStaticKind { MAC_STATIC_NONE = 0, MAC_STATIC_ONE = 1, MAC_STATIC_PAIR = 2, MAC_STATIC_LDS = 3, MAC_STATIC_LDS_UNITS = 4 };
+
+struct MacPlan {
+  int static_kind;    // MacStaticKind: which capsule-loop kernel takes the one-emitter events (NONE: the tile kernel does)
+  int static_pt;      // its PT template argument
+  dim3 static_grid;
+  int static_threads;
+  int static_code;    // what al_spectral_mac_variant reports for one-emitter events
+  int tile_code;      // k_spectral_mac instantiation (0: not launched)
+  int moving_code;    // k_spectral_mac_moving instantiation (0: not launched)
+};
+
+MacPlan plan_mac(const al_batch *b) {
+  MacPlan m{};
+  const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
+  const int bins = 1 << b->log2_block;
+  // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers
+  // (sweep of other shapes: profiles/r01_mac_variants.txt)
+  if (wide_k && wide_p && bins >= 512) m.tile_code = 1121202;
+  else if (wide_k) m.tile_code = 240401;
+  else if (wide_p) m.tile_code = 81201;
+  else m.tile_code = 80401;
+  // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
+  if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS)
+    m.moving_code = 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
+  m.static_code = m.tile_code;
+  if (al::static_mac_active(*b)) {
+    const int P = b->n_partitions;
+    // enough workgroups to fill the chip: split the capsule loop for small batches
+    const int n_ktiles = (b->max_blocks + 11) / 12, base = (bins / 512) * n_ktiles * b->n_events;
+    int n_cs = 1;
+    while (n_cs < b->n_capsules && base * n_cs < 1024) n_cs *= 2;
+    if (n_cs > b->n_capsules) n_cs = b->n_capsules;
+    // flags bit 12 (A/B switch): one k-tile per workgroup; bit 13 (A/B switch): register version beyond 24 blocks
+    const bool pair = n_ktiles > 1 && !(b->flags & (1 << 12));
+    const int n_pairs = (n_ktiles + 1) / 2;
+    if (P > 12) {   // 13..16 partitions: two units of ceil(P/2) per capsule, always through LDS, always two k-tiles per workgroup
+      m.static_kind = MAC_STATIC_LDS_UNITS;
+      m.static_pt = (P + 1) / 2;
+      m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
+      m.static_threads = 512;
+    } else if (pair && n_pairs > 1 && !(b->flags & (1 << 13))) {
+      m.static_kind = MAC_STATIC_LDS;
+      m.static_pt = P;
+      m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
+      m.static_threads = 512;
+    } else if (pair) {
+      m.static_kind = MAC_STATIC_PAIR;
+      m.static_pt = P;
+      m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
+      m.static_threads = 512;
+    } else {
+      m.static_kind = MAC_STATIC_ONE;
+      m.static_pt = P;
+      m.static_grid = dim3(bins / 512, n_ktiles, b->n_events * n_cs);
+      m.static_threads = 256;
+    }
+    m.static_code = 3120000 + 100 * P + (m.static_kind == MAC_STATIC_ONE ? 1 : m.static_kind == MAC_STATIC_PAIR ? 2 : 3);
+    if (b->flags & AL_FLAG_ONLY_STATIC) m.tile_code = m.moving_code = 0;   // no event is left for the other kernels
+  }
+  return m;
+}
+
+template <int PT>
+void launch_mac_static(const MacPlan &m, const al_batch *b, hipStream_t stream) {
+  switch (m.static_kind) {
+    case MAC_STATIC_ONE:
+      hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT, 1>), m.static_grid, dim3(256), 0, stream, *b);
+      break;
+    case MAC_STATIC_PAIR:
+      hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT, 2>), m.static_grid, dim3(512), 0, stream, *b);
+      break;
+    default:
+      hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT>), m.static_grid, dim3(512), 0, stream, *b);
+      break;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 const char *al_last_error(void) { return g_err; }
-int al_abi_version(void) { return 1; }
+int al_abi_version(void) { return AL_ABI_VERSION; }
 
 int64_t al_twiddle_bytes(int log2_block) {
   if (log2_block < AL_MIN_LOG2_BLOCK || log2_block > AL_MAX_LOG2_BLOCK) return -1;
@@ -1049,116 +1145,58 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream) {
   return check_error(al::launch_signal_spectra(b, (hipStream_t)stream), "k_signal_spectra");
 }
 
-// Which instantiations al_spectral_mac launches for a batch.  Static code = 1000000*KSPLIT + 10000*KT + 100*PT + VB of
-// k_spectral_mac<KT,PT,VB,KSPLIT>; moving code = 100*NJW + PT of k_spectral_mac_moving<NJW,PT,1> (0: not launched).
-static bool static_pair(const al_batch *b) {   // two k-tiles per workgroup (flags bit 12: experiment switch, one per workgroup)
-  return (b->max_blocks + 11) / 12 > 1 && !(b->flags & (1 << 12));
-}
-
-static void pick_mac(const al_batch *b, int32_t *static_code, int32_t *moving_code) {
-  const int variant = (b->flags >> 8) & 15;
-  const bool wide_k = b->max_blocks > 8, wide_p = b->n_partitions > 4;
-  const int bins = 1 << b->log2_block;
-  int code;
-  if (variant == 11) code = 1121202;
-  else if (variant == 12) code = 1081202;
-  else if (variant == 13) code = 1121201;
-  else if (variant == 14) code = 1061202;
-  else if (variant == 15) code = 1241201;
-  else if (variant == 1) code = 121201;
-  else if (variant == 2) code = 121202;  // k-tiles looped inside the thread
-  else if (variant == 3) code = 81202;
-  else if (variant == 4) code = 241202;
-  else if (variant == 5) code = 81201;
-  else if (variant == 6) code = 241201;
-  else if (wide_k && wide_p && bins >= 512) code = 1121202;  // fastest on cfg2 (profiles/r01_mac_variants.txt)
-  else if (wide_k) code = 240401;
-  else if (wide_p) code = 81201;
-  else code = 80401;
-  *static_code = code;
-  // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
-  *moving_code = 0;
-  if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS)
-    *moving_code = 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
-}
-
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code) {
   if (int rc = check_batch(b)) return rc;
   if (!static_code || !moving_code) return fail(AL_E_BADARG, "null output");
-  pick_mac(b, static_code, moving_code);
-  // one-emitter events through k_spectral_mac_static<12, PT = P, NKTW>: 3000000 + 10000*12 + 100*PT + NKTW
-  // (the tile kernel pick_mac names then only sees multi-emitter events, if the batch has any)
-  // NKTW digit: 1 = one k-tile per workgroup, 2 = two, 3 = two with the partition spectra staged through LDS (more than 24 blocks)
-  if (al::static_mac_active(*b)) {
-    const bool lds_ring = b->n_partitions > 12 || (static_pair(b) && (b->max_blocks + 23) / 24 > 1 && !(b->flags & (1 << 13)));
-    *static_code = 3000000 + 120000 + 100 * b->n_partitions + (lds_ring ? 3 : static_pair(b) ? 2 : 1);
-  }
+  const MacPlan m = plan_mac(b);
+  *static_code = m.static_code;
+  *moving_code = m.moving_code;
   return AL_OK;
 }
 
-int al_spectral_mac(const al_batch *b, al_stream_t stream) {
+int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
   if (int rc = check_batch(b)) return rc;
   if (b->n_events <= 0 || b->n_emitters <= 0) return AL_OK;
-  // tile shapes: accumulators for up to 24 output blocks, 4 or 12 partition spectra in registers.
-  // flags bits 8..11 select an experimental variant (0 = default).
-  int32_t code, moving;
-  pick_mac(b, &code, &moving);
+  hipStream_t stream = (hipStream_t)stream_;
+  const MacPlan m = plan_mac(b);
   const int bins = 1 << b->log2_block;
-  if (al::static_mac_active(*b)) {
-    // enough workgroups to fill the chip: split the capsule loop for small batches
-    const int n_ktiles = (b->max_blocks + 11) / 12, base = (bins / 512) * n_ktiles * b->n_events;
-    int n_cs = 1;
-    while (n_cs < b->n_capsules && base * n_cs < 1024) n_cs *= 2;
-    if (n_cs > b->n_capsules) n_cs = b->n_capsules;
-    const int P = b->n_partitions;
-    const bool pair = static_pair(b);
-    const dim3 grid(bins / 512, pair ? (n_ktiles + 1) / 2 : n_ktiles, b->n_events * n_cs);
-    const bool lds_ring = pair && grid.y > 1 && !(b->flags & (1 << 13));   // flags bit 13: A/B switch, register version
-    switch (P) {   // the partition tile IS the partition count: no masked partitions in the loop
-#define AL_STATIC(PT_) \
-    case PT_: \
-      if (lds_ring) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT_>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
-      else if (pair) hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 2>), grid, dim3(512), 0, (hipStream_t)stream, *b); \
-      else hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT_, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b); \
-      break
-      AL_STATIC(1); AL_STATIC(2); AL_STATIC(3); AL_STATIC(4); AL_STATIC(5); AL_STATIC(6);
-      AL_STATIC(7); AL_STATIC(8); AL_STATIC(9); AL_STATIC(10); AL_STATIC(11); AL_STATIC(12);
-#define AL_STATIC2(PT_) \
-    case 2 * PT_ - 1: case 2 * PT_: /* 13..16 partitions: two units of PT_ per capsule, always through LDS */ \
-      hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT_, 2>), dim3(grid.x, (n_ktiles + 1) / 2, grid.z), dim3(512), 0, \
-                         (hipStream_t)stream, *b); \
-      break
-      AL_STATIC2(7); AL_STATIC2(8);   // 17..24 partitions: the window (KT + P - 1 blocks) no longer fits beside the accumulators
-#undef AL_STATIC2
-      default: return fail(AL_E_BADARG, "capsule-loop accumulate: more than 16 partitions");
+  if (m.static_kind == MAC_STATIC_LDS_UNITS) {
+    if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    if (int rc = check_launch("k_spectral_mac_static_lds")) return rc;
+  } else if (m.static_kind != MAC_STATIC_NONE) {
+    switch (m.static_pt) {   // the partition tile IS the partition count: no masked partitions in the loop
+      case 1: launch_mac_static<1>(m, b, stream); break;
+      case 2: launch_mac_static<2>(m, b, stream); break;
+      case 3: launch_mac_static<3>(m, b, stream); break;
+      case 4: launch_mac_static<4>(m, b, stream); break;
+      case 5: launch_mac_static<5>(m, b, stream); break;
+      case 6: launch_mac_static<6>(m, b, stream); break;
+      case 7: launch_mac_static<7>(m, b, stream); break;
+      case 8: launch_mac_static<8>(m, b, stream); break;
+      case 9: launch_mac_static<9>(m, b, stream); break;
+      case 10: launch_mac_static<10>(m, b, stream); break;
+      case 11: launch_mac_static<11>(m, b, stream); break;
+      case 12: launch_mac_static<12>(m, b, stream); break;
+      default: return fail(AL_E_BADARG, "capsule-loop accumulate: bad partition tile");
     }
-#undef AL_STATIC
     if (int rc = check_launch("k_spectral_mac_static")) return rc;
-    if (b->flags & AL_FLAG_ONLY_STATIC) return AL_OK;   // no event is left for the tile / sliding-window kernels
   }
 #define AL_MAC(KT_, PT_, VB_) \
   case 10000 * KT_ + 100 * PT_ + VB_: \
     hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_>), dim3(bins / (256 * VB_), b->n_capsules, b->n_events), dim3(256), 0, \
-                       (hipStream_t)stream, *b); \
+                       stream, *b); \
     break
 #define AL_MAC_KS(KT_, PT_, VB_) \
   case 1000000 + 10000 * KT_ + 100 * PT_ + VB_: \
     hipLaunchKernelGGL((al::k_spectral_mac<KT_, PT_, VB_, true>), \
                        dim3(bins / (256 * VB_), b->n_capsules * ((b->max_blocks + KT_ - 1) / KT_), b->n_events), dim3(256), 0, \
-                       (hipStream_t)stream, *b); \
+                       stream, *b); \
     break
-  switch (code) {
+  switch (m.tile_code) {
+    case 0: break;   // AL_FLAG_ONLY_STATIC: every event went through the capsule loop
     AL_MAC_KS(12, 12, 2);
-    AL_MAC_KS(8, 12, 2);
-    AL_MAC_KS(12, 12, 1);
-    AL_MAC_KS(6, 12, 2);
-    AL_MAC_KS(24, 12, 1);
-    AL_MAC(12, 12, 1);
-    AL_MAC(12, 12, 2);
-    AL_MAC(8, 12, 2);
-    AL_MAC(24, 12, 2);
     AL_MAC(8, 12, 1);
-    AL_MAC(24, 12, 1);
     AL_MAC(24, 4, 1);
     AL_MAC(8, 4, 1);
     default: return fail(AL_E_UNSUPPORTED, "unknown spectral MAC variant");
@@ -1166,13 +1204,13 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream) {
 #undef AL_MAC
 #undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
-  if (moving) {
+  if (m.moving_code) {
     const dim3 grid(bins / 256, b->n_capsules, b->n_events);
-    if (moving % 100 == 12)
-      hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, 12, 1>), grid, dim3(256), 0, (hipStream_t)stream, *b);
+    if (m.moving_code % 100 == 12)
+      hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, 12, 1>), grid, dim3(256), 0, stream, *b);
     else
       hipLaunchKernelGGL((al::k_spectral_mac_moving<AL_SPARSE_MAX_NJ, AL_SPARSE_MAX_PARTITIONS, 1>), grid, dim3(256), 0,
-                         (hipStream_t)stream, *b);
+                         stream, *b);
     return check_launch("k_spectral_mac_moving");
   }
   return AL_OK;
@@ -1232,7 +1270,10 @@ int al_render_batch(const al_batch *b, al_stream_t stream) {
 }
 
 int al_mixdown(const al_mix *m, al_stream_t stream) {
-  if (!m || m->n_capsules <= 0 || m->n_samples <= 0 || m->tile <= 0) return fail(AL_E_BADARG, "bad mixdown arguments");
+  if (!m) return fail(AL_E_BADARG, "null mixdown descriptor");
+  if (m->struct_size != (int32_t)sizeof(al_mix) || m->abi_version != AL_ABI_VERSION)
+    return fail(AL_E_BADARG, "al_mix was built against another version of audiblelight_hip.h (struct_size / abi_version)");
+  if (m->n_capsules <= 0 || m->n_samples <= 0 || m->tile <= 0) return fail(AL_E_BADARG, "bad mixdown arguments");
   if (m->tile != 4096) return fail(AL_E_BADARG, "mixdown tile must be 4096 samples");
   if (m->n_tiles != (m->n_samples + m->tile - 1) / m->tile) return fail(AL_E_BADARG, "n_tiles != ceil(n_samples / tile)");
   if (((uintptr_t)m->scene & 15) != 0) return fail(AL_E_BADARG, "scene buffer must be 16-byte aligned");

@@ -17,11 +17,9 @@ from .plan import BatchPlan, MixPlan
 
 
 def _debug_flags() -> int:
-    """Experimental kernel switches from the environment (AL_MAC_VARIANT, AL_EXTRA_FLAGS), masked to the bits that
-    select code paths with identical results; bit 0 (AL_FLAG_NO_IR_NORM) changes results and is never taken from it."""
-    variant = int(os.environ.get("AL_MAC_VARIANT", "0")) & 15
-    extra = int(os.environ.get("AL_EXTRA_FLAGS", "0")) & _hip.DEBUG_FLAG_MASK
-    return (variant << 8) | extra
+    """Experimental kernel switches from the environment (AL_EXTRA_FLAGS), masked to the bits that select code paths
+    with identical results; bit 0 (AL_FLAG_NO_IR_NORM) changes results and is never taken from it."""
+    return int(os.environ.get("AL_EXTRA_FLAGS", "0")) & _hip.DEBUG_FLAG_MASK
 
 
 # ----------------------------------------------------------------------------- memory providers

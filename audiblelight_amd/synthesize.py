@@ -194,12 +194,12 @@ def normalize_irs(irs: np.ndarray) -> np.ndarray:
 
 
 # ----------------------------------------------------------------------------- event rendering
-def _clip_of(event, ignore_cache: bool):
+def _clip_of(event, ignore_cache: bool, chain_is_fresh: bool = False):
     """The event's clip for the renderer: ``engine.ClipSource`` from events that can hand it over without a host
     round trip (core.Event.clip_source: device FX chain, folded Gain/Invert + peak normalisation), else the array
     ``event.load_audio()`` returns (reference Events: event.py:496-539)."""
     if hasattr(event, "clip_source"):
-        return event.clip_source(ignore_cache=ignore_cache)
+        return event.clip_source(ignore_cache=ignore_cache, chain_is_fresh=chain_is_fresh)
     audio = event.load_audio(ignore_cache=ignore_cache, normalize=True)
     valid_audio(audio)
     return np.ascontiguousarray(audio, dtype=np.float32)
@@ -308,14 +308,22 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
     irs = scene.state.get_irs()
     start = time()
     r = get_renderer()
-    for mic_alias, mic_ir in irs.items():
+    from .core import stage_event_chains
+
+    for n_mic, (mic_alias, mic_ir) in enumerate(irs.items()):
+        # FX chains that have to run on the device: raw clips through one staging arena + one DMA (once per scene; with
+        # ignore_cache every microphone draws a fresh realisation, as the reference's per-microphone load_audio does)
+        if n_mic == 0 or ignore_cache:
+            fresh = stage_event_chains([ev for ev in scene.events.values()
+                                        if ignore_cache or mic_alias not in getattr(ev, "spatial_audio", {}).keys()],
+                                       bool(ignore_cache))
         specs, clips, todo = [], [], []
         counter = 0
         for event in scene.events.values():
             n_emit = len(event)
             cached = mic_alias in getattr(event, "spatial_audio", {}).keys() and not ignore_cache
             if not cached:
-                clip = _clip_of(event, bool(ignore_cache))
+                clip = _clip_of(event, bool(ignore_cache), any(event is f for f in fresh))
                 specs.append(_spec_of(event, clip, n_emit, counter, scene.ref_db))
                 clips.append(clip)
                 todo.append((event, counter))
@@ -404,7 +412,7 @@ def generate_scene_audio_from_events(scene) -> None:
 
 def encode_scene_frames(scene, mic_alias: str, subtype: str = "PCM_16") -> np.ndarray:
     """(T, C) frames of ``scene.audio[mic]`` as ``soundfile.write(audio.T, sr)`` stores them (core.py:1840-1847):
-    int16 for ``PCM_16`` (soundfile's default subtype for WAV; lrint(x * 32767), saturated) or float32 for ``FLOAT``.
+    int16 for ``PCM_16`` (soundfile's default subtype for WAV; lrintf(x * 32768) saturated to int16: libsndfile with clipping on, as python-soundfile sets it) or float32 for ``FLOAT``.
     Interleaving and quantisation run on the device, from the resident mix when ``scene.audio[mic]`` is still the
     array this package produced, else from an upload of it."""
     from . import _hip

@@ -27,7 +27,7 @@ def main(out_dir="quickstart_out"):
                                augmentations=[augmentation.Gain(sr, gain_db=-3.0), augmentation.Fade(sr, 0.1, 0.3, "linear", "half_sine")]))
     scene.add_event(core.Event("moving", rng.standard_normal(4 * sr).astype(np.float32), sr, snr=20, scene_start=4.0, n_emitters=4))
     scene.add_ambience(ambience.Ambience(channels=n_caps, duration=10.0, alias="pink", noise="pink", ref_db=-70, sample_rate=sr))
-    audio = scene.generate(output_dir=out_dir)
+    audio = scene.generate(output_dir=out_dir, metadata_dcase=False)   # events from bare arrays carry no DCASE class indices
     for mic, buf in audio.items():
         print(f"{mic}: {buf.shape} float32, peak {np.abs(buf).max():.3e} -> {out_dir}/audio_out_{mic}.wav")
     json_path = os.path.join(out_dir, "scene.json")

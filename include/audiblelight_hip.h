@@ -24,6 +24,12 @@
 extern "C" {
 #endif
 
+/* Version of THIS header's struct layouts and entry points.  al_abi_version() returns the value the library was built
+ * with; a host must compare it with the AL_ABI_VERSION it was compiled against before passing any struct (al_batch and
+ * al_mix grew fields in version 2: clip_scale, xspec/hspec_zero_block, ambience, ambience_scale; version 3 puts
+ * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread). */
+#define AL_ABI_VERSION 3
+
 #define AL_OK 0
 #define AL_E_BADARG (-1)
 #define AL_E_HIP (-2)
@@ -89,6 +95,8 @@ typedef struct {
 
 /* Everything one launch sequence needs.  All pointers are device pointers unless noted. */
 typedef struct {
+  int32_t struct_size;  /* sizeof(al_batch) as the CALLER compiled it, and the AL_ABI_VERSION it was compiled against: every */
+  int32_t abi_version;  /* entry point refuses a descriptor whose two fields differ from the library's own (AL_E_BADARG) */
   int32_t log2_block;   /* B = 1 << log2_block */
   int32_t n_capsules;   /* C */
   int32_t n_events;     /* E */
@@ -139,6 +147,8 @@ typedef struct {
 
 /* Mixdown of one microphone (generate_scene_audio_from_events, synthesize.py:314-401). */
 typedef struct {
+  int32_t struct_size;    /* sizeof(al_mix) and AL_ABI_VERSION as the caller compiled them (checked like al_batch's) */
+  int32_t abi_version;
   int32_t n_capsules;     /* rows of the scene buffer */
   int32_t n_samples;      /* round(scene.duration * sample_rate) (synthesize.py:331) */
   int32_t tile;           /* samples per time tile: 4096 */
@@ -175,12 +185,14 @@ int al_signal_spectra(const al_batch *b, al_stream_t stream);  /* A13 gain + A7 
 int al_forward_spectra(const al_batch *b, al_stream_t stream); /* al_ir_spectra + al_signal_spectra (independent of each other):
                                                                   one launch in the split layout, else the two in turn */
 int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequency-domain accumulate */
-/* Which kernel instantiations al_spectral_mac launches for this batch (no launch; used by the parity tests to assert
- * the regime they cover).  *static_code = the kernel that takes one-emitter events: 1000000*KSPLIT + 10000*KT + 100*PT + VB
- * (k-tile, partition tile, bins per thread of the tile kernel), or 3120000 + 100*PT + NKTW for the capsule-loop
- * kernel k_spectral_mac_static<12, PT = partitions, k-tiles per workgroup> (NKTW digit 3: two k-tiles with the partition
- * spectra staged through LDS, k_spectral_mac_static_lds: clips of more than 24 blocks, and 13..16 partitions as two units per capsule) (AL_FLAG_STATIC_MAC and at
- * most 16 partitions); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not launched. */
+/* Which kernel instantiations al_spectral_mac launches for this batch (no launch; the launcher and this call read the
+ * SAME descriptor, so the parity tests' assertion of the regime they cover cannot drift).  *static_code = the kernel that
+ * takes one-emitter events: 1000000*KSPLIT + 10000*KT + 100*PT + VB (k-tile, partition tile, bins per thread of the tile
+ * kernel k_spectral_mac), or 3120000 + 100*P + D for the capsule-loop kernels (AL_FLAG_STATIC_MAC, P <= 16 partitions):
+ * D = 1: k_spectral_mac_static<12,P,1> (clips of at most 12 blocks), 2: <12,P,2> (13..24 blocks), 3: the partition spectra
+ * staged through LDS, k_spectral_mac_static_lds<12,P> (more than 24 blocks) or <12,ceil(P/2),2> (13..16 partitions as two
+ * units per capsule, any clip length); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 0 = not
+ * launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 /* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.
@@ -298,7 +310,8 @@ int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *ta
 
 /* Output encoding for the WAV writer: (C, T) float32 scene -> (T, C) interleaved frames as
  * soundfile.write(mic_audio.T, sr) stores them (core.py:1840-1847).  AL_FRAMES_PCM16 is soundfile's default subtype for
- * WAV: int16 = lrint(x * 32767) (libsndfile's float->short normalisation), saturated; AL_FRAMES_F32 keeps float32.
+ * WAV: python-soundfile enables clipping on every file, so libsndfile's f2s_clip_array applies: int16 = lrintf(x * 32768)
+ * saturated to [-32768, 32767]; AL_FRAMES_F32 keeps float32.
  * Done on the device so the D2H copy is already the file payload (half the bytes for PCM_16).  `out` may be page-locked host
  * memory; capsule counts that are multiples of 8 (PCM_16) / 4 (float32) are stored 16 bytes per lane and need a 16-byte
  * aligned `out`. */

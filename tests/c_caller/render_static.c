@@ -97,8 +97,14 @@ int main(int argc, char **argv) {
   hipStream_t stream;
   HIP_OK(hipStreamCreate(&stream));
   const size_t blk = (size_t)B * 8; /* one block spectrum: B complex floats */
+  if (al_abi_version() != AL_ABI_VERSION) {   /* the library must implement the header this host was compiled against */
+    fprintf(stderr, "libaudiblelight_hip implements ABI %d, this host was compiled against %d\n", al_abi_version(), AL_ABI_VERSION);
+    return 3;
+  }
   al_batch b;
   memset(&b, 0, sizeof b);
+  b.struct_size = (int32_t)sizeof b;
+  b.abi_version = AL_ABI_VERSION;
   b.log2_block = lb, b.n_capsules = C, b.n_events = E, b.n_streams = E, b.n_emitters = E, b.ir_len = Lir;
   b.ir_stride_c = (int64_t)E * ir_pitch, b.ir_stride_n = ir_pitch;
   b.n_partitions = P, b.max_blocks = K, b.max_nj = K, b.hop = 128;
@@ -147,6 +153,8 @@ int main(int argc, char **argv) {
   HIP_OK(hipMemcpyAsync(d_src, slot_src, 8 * E, hipMemcpyHostToDevice, stream));
   al_mix m;
   memset(&m, 0, sizeof m);
+  m.struct_size = (int32_t)sizeof m;
+  m.abi_version = AL_ABI_VERSION;
   m.n_capsules = C, m.n_samples = La, m.tile = tile, m.n_tiles = n_tiles, m.accumulate = 0;
   m.tile_ptr = d_tp, m.tile_events = d_te, m.slot_src = d_src;
   m.slot_len = d_i32, m.slot_start = d_i32 + E, m.slot_count = d_i32 + 2 * E, m.slot_rows = d_i32 + 3 * E, m.slot_event = d_i32 + 4 * E;

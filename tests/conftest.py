@@ -27,3 +27,10 @@ def rel_rms(a, b):
     b = np.asarray(b, dtype=np.float64)
     den = np.sqrt(np.mean(b ** 2))
     return float(np.sqrt(np.mean((a - b) ** 2)) / (den if den > 0 else 1.0))
+
+
+def pcm16(x):
+    """float32 -> int16 as python-soundfile writes PCM_16 (libsndfile f2s_clip_array, clipping on): lrintf(x * 32768),
+    saturated to [-32768, 32767]."""
+    scaled = np.asarray(x, dtype=np.float32) * np.float32(32768.0)
+    return np.clip(np.rint(scaled), -32768, 32767).astype(np.int16)

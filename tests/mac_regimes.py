@@ -25,6 +25,54 @@ STATIC_CASES = [
     ("tile_8_4_1", 80401, 3.0, 2.0),                 # exact multiples: K = 3, P = 2
 ]
 
+# k_spectral_mac_static<12,P,{1,2}> / k_spectral_mac_static_lds<12,P> / <12,ceil(P/2),2>: EVERY partition count 1..16 in each of
+# the three clip-length regimes that pick a different instantiation (or, for 13..16 partitions, a different grid of the same one):
+# (name, expected code 3120000 + 100*P + {1: one k-tile per workgroup, 2: two, 3: partition spectra staged through LDS},
+#  K multiple, P multiple, capsules, events); one event => the capsule loop is split into ranges (small batch)
+_CLIP_REGIMES = (("one_ktile", 9.3, 1), ("two_ktiles", 20.6, 2), ("beyond_24_blocks", 26.3, 3))
+STATIC_LOOP_CASES = [
+    (f"P{P}_{name}", 3120000 + 100 * P + (3 if P > 12 else digit), k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
+    for P in range(1, 17) for name, k_mult, digit in _CLIP_REGIMES]
+STATIC_LOOP_CASES += [   # hand-picked edges kept from round 2
+    ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
+    ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
+    ("three_ktiles_idle_half", 3121203, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles in 2 workgroups, the last has an idle half
+    ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
+    ("two_units_16_long", 3121603, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
+    ("two_units_one_ktile", 3121403, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
+]
+MOVING_CODES = [612, 624]       # asserted by test_moving_regimes / test_cfg3_regime_all_rows
+# codes the GPU tests assert beyond the tables above: cfg4's <12,6,2>, cfg5's tile kernel with two full partition tiles
+EXTRA_STATIC_CODES = [3120602, 1121202]
+
+
+def codes_of_kernel_symbol(sym: str):
+    """Demangled kernel name (``nm -C``) -> the al_spectral_mac_variant codes under which it runs, as (kind, code) pairs."""
+    import re
+
+    m = re.search(r"k_spectral_mac(_static_lds|_static|_moving)?<([0-9, a-z]+)>", sym)
+    if not m:
+        return []
+    kind, args = m.group(1) or "", [a.strip() for a in m.group(2).split(",")]
+    if kind == "":
+        kt, pt, vb = int(args[0]), int(args[1]), int(args[2])
+        return [("static", (1000000 if args[3] == "true" else 0) + 10000 * kt + 100 * pt + vb)]
+    if kind == "_moving":
+        return [("moving", 100 * int(args[0]) + int(args[1]))]
+    pt, last = int(args[1]), int(args[2])
+    if kind == "_static":
+        return [("static", 3120000 + 100 * pt + last)]
+    if last == 1:
+        return [("static", 3120000 + 100 * pt + 3)]
+    return [("static", 3120000 + 100 * p + 3) for p in (2 * pt - 1, 2 * pt)]   # two units per capsule: P = 2*PT - 1 and 2*PT
+
+
+def asserted_codes():
+    """Every (kind, code) some -m gpu test asserts through al_spectral_mac_variant."""
+    out = {("static", c[1]) for c in STATIC_CASES} | {("static", c[1]) for c in STATIC_LOOP_CASES}
+    out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES}
+    return out
+
 
 def mac_codes(renderer, batch, chunk=0):
     s, m = ct.c_int32(-1), ct.c_int32(-1)

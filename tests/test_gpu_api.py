@@ -57,3 +57,4 @@ test_fx_match_the_reference_classes_outputs = scenarios.test_fx_match_the_refere
 test_ambience_file_mode_matches_the_reference = scenarios.test_ambience_file_mode_matches_the_reference
 test_big_batches_chunk_themselves = scenarios.test_big_batches_chunk_themselves
 test_dcase_metadata_matches_the_reference_function = scenarios.test_dcase_metadata_matches_the_reference_function
+test_one_fx_realisation_per_event_across_microphones = scenarios.test_one_fx_realisation_per_event_across_microphones

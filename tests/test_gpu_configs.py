@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import synth_oracle as orc
-from tests.conftest import rel_rms
+from tests.conftest import pcm16, rel_rms
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -93,6 +93,49 @@ def test_cfg5_64ch_ambience_and_folded_fx(gpu):
         syn.set_renderer(None)
 
 
+def test_cfg5_regime_all_rows(gpu):
+    """cfg5's own kernel regime at FULL length: B = 8192, P = 24 partitions (4 s RIR) -> k_spectral_mac<12,12,2,KSPLIT> with
+    two full partition tiles, K = 24, C = 64 capsules, clip scales folded on the device, the ambience fused into the mixdown
+    over the whole 60 s scene.  2 events built from core.Event(augmentations=[Gain, Invert]) + a white Ambience through
+    Scene.generate(); the scene and EVERY row of every event against the oracle."""
+    from audiblelight_amd import ambience as amb, augmentation as aug, core, plan as planning, synthetic
+    from audiblelight_amd import synthesize as syn
+    from tests import mac_regimes as mr
+
+    sc = synthetic.make_scene("cfg5", E=2)
+    assert sc.n_capsules == 64 and sc.ir_len == 192000 and len(sc.clips[0]) == 192000 and sc.duration == 60.0
+    pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)
+    assert pl.log2_block == 13 and pl.n_partitions == 24 and int(pl.events["n_blocks"].max()) == 24
+    batch = gpu.prepare(pl, sc.sources(), sc.irs)
+    assert mr.mac_codes(gpu, batch) == (1121202, 0) and mr.is_split(batch)
+    want_events = [oracle_event(sc, i) for i in range(2)]
+    res = batch.run()
+    res.check_finite()
+    for i in range(2):
+        mr.check_event_rows(res, i, want_events[i])
+    del res, batch
+    syn.set_renderer(gpu)
+    try:
+        scene = core.Scene(sc.duration, core.StaticIRState({"em64": sc.irs}), sample_rate=sc.sr, ref_db=-65)
+        for i, (raw, sp) in enumerate(zip(sc.clips, sc.specs)):
+            scene.add_event(core.Event(f"e{i}", raw, sc.sr, snr=sp.snr, scene_start=sc.starts[i],
+                                       augmentations=[aug.Gain(sc.sr, gain_db=sc.gain_db[i]), aug.Invert(sc.sr)]))
+        scene.add_ambience(amb.Ambience(channels=64, duration=sc.duration, alias="a", noise="white", ref_db=-65, sample_rate=sc.sr))
+        got = scene.generate()["em64"]
+        assert got.shape == (64, 2880000) and got.dtype == np.float32
+        for i, ev in enumerate(scene.events.values()):
+            rows = ev.spatial_audio["em64"]
+            for c in range(64):
+                assert rel_rms(rows[c], want_events[i][c]) < TOL, (i, c)
+        noise = orc.ambience_noise(0, 64, sc.duration, sc.sr)
+        want = orc.mix_scene(want_events, list(zip(sc.starts, sc.ends)), sc.duration, sc.sr, ambiences=[(noise, -65)],
+                             keep_padded=False)["scene"]
+        for c in range(64):
+            assert rel_rms(got[c], want[c]) < TOL, c
+    finally:
+        syn.set_renderer(None)
+
+
 def oracle_scene(sc):
     n = len(sc.specs)
     return orc.mix_scene([oracle_event(sc, i) for i in range(n)], list(zip(sc.starts, sc.ends)), sc.duration, sc.sr,
@@ -102,7 +145,7 @@ def oracle_scene(sc):
 def test_batch_driver_writes_what_the_oracle_mixes(gpu, tmp_path):
     """the pipelined multi-scene driver (H2D / render / device-side frame encoding / D2H / WAV writer)
     against the ORACLE's scenes: float32 frames within the parity tolerance, PCM_16 frames (soundfile's default subtype,
-    core.py:1840-1847) within one LSB of lrint(oracle * 32767); float64 IRs (cast in the planner stage, one with an odd row length) and float32 IRs;
+    core.py:1840-1847) within one LSB of lrint(oracle * 32768); float64 IRs (cast in the planner stage, one with an odd row length) and float32 IRs;
     skip_existing leaves written scenes alone (benchmark.py:54-55)."""
     from scipy.io import wavfile
 
@@ -128,10 +171,10 @@ def test_batch_driver_writes_what_the_oracle_mixes(gpu, tmp_path):
     for i, sc in enumerate(scenes):
         sr, wav = wavfile.read(str(tmp_path / "pcm" / f"s{i}.wav"))
         assert wav.dtype == np.int16 and wav.shape == want[i].T.shape
-        ref = np.rint(want[i].T.astype(np.float64) * 32767.0)
+        ref = np.clip(np.rint(want[i].T.astype(np.float64) * 32768.0), -32768, 32767)
         assert np.abs(wav.astype(np.float64) - ref).max() <= 1
         # bit-exact against the encoder's definition applied to the float32 scene the device held
-        np.testing.assert_array_equal(wav, np.clip(np.rint(got[f"s{i}"].T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16))
+        np.testing.assert_array_equal(wav, pcm16(got[f"s{i}"].T))
     again = drv.run(jobs, output_dir=str(tmp_path / "pcm"), skip_existing=True)
     assert again.n_scenes == 0 and sorted(again.skipped) == [f"s{i}" for i in range(4)]
 
@@ -174,6 +217,39 @@ def test_batch_driver_reports_writer_failures(gpu, tmp_path, monkeypatch):
     monkeypatch.setattr(gpu, "upload_irs", flaky)
     with pytest.raises(MemoryError, match="upload failed"):
         drv.run(jobs[3:], on_scene=lambda n, a: None)
+
+
+def test_batch_driver_slow_writer_keeps_its_buffer(gpu, tmp_path, monkeypatch):
+    """Writers finish out of order: while one of four writer threads sits in a slow ``wavfile.write`` the driver renders a
+    dozen more scenes.  Its page-locked frame buffer must not be handed to a later scene's D2H copy before it is done
+    (buffers come from a free list, batch.BatchDriver.run): the frames it writes AFTER the stall must still be its own."""
+    import time
+
+    from scipy.io import wavfile
+
+    from audiblelight_amd import batch, synthetic
+
+    scenes = [synthetic.make_scene("cfg1", scene_index=i, scale=0.25) for i in range(14)]
+    jobs = [batch.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs, starts=sc.starts, ends=sc.ends, duration=sc.duration,
+                           sample_rate=sc.sr, name=f"s{i}") for i, sc in enumerate(scenes)]
+    real_write, torn = wavfile.write, []
+
+    def slow_write(path, rate, data):
+        if path.endswith("s0.wav") or path.endswith("s5.wav"):
+            before = np.array(data, copy=True)
+            time.sleep(0.8)                       # twelve other scenes pass through the other writers meanwhile
+            if not np.array_equal(before, data):
+                torn.append(path)
+        return real_write(path, rate, data)
+
+    monkeypatch.setattr(wavfile, "write", slow_write)
+    got = {}
+    rep = batch.BatchDriver(gpu, depth=2, writers=4).run(jobs, output_dir=str(tmp_path), on_scene=got.__setitem__, subtype="FLOAT")
+    assert rep.n_scenes == 14 and not torn
+    for i in range(14):
+        _, wav = wavfile.read(str(tmp_path / f"s{i}.wav"))
+        np.testing.assert_array_equal(wav.T, got[f"s{i}"])
+    assert rel_rms(got["s0"], oracle_scene(scenes[0])) < TOL and rel_rms(got["s13"], oracle_scene(scenes[13])) < TOL
 
 
 def test_render_dataset_layout_and_audio(gpu, tmp_path):
@@ -232,6 +308,12 @@ def test_render_dataset_layout_and_audio(gpu, tmp_path):
                 assert rel_rms(wav.T, want) < TOL
         again = batch.render_dataset(((f"scene_{i:03d}", factory(i)) for i in range(4)), str(tmp_path), subtype="FLOAT")
         assert again.n_scenes == 2 and built == [0, 1, 2, 3] and sorted(again.skipped) == ["scene_000", "scene_001", "scene_002"]
+        # a folder an interrupted run left WITHOUT its metadata file (written last) is not "done": it is rendered again
+        os.remove(tmp_path / "scene_001" / "metadata_out.json")
+        os.remove(tmp_path / "scene_001" / "audio_out_mic_b.wav")
+        redo = batch.render_dataset(((f"scene_{i:03d}", factory(i)) for i in range(4)), str(tmp_path), subtype="FLOAT")
+        assert redo.n_scenes == 2 and built == [0, 1, 2, 3, 1] and sorted(redo.skipped) == ["scene_000", "scene_002", "scene_003"]
+        assert (tmp_path / "scene_001" / "metadata_out.json").exists() and (tmp_path / "scene_001" / "audio_out_mic_b.wav").exists()
         # one process per GPU, same stream of scenes: rank r renders every world_size-th scene into the shared folder and
         # never builds the others (two "ranks" run one after the other here; there is no collective to wait for)
         del built[:]

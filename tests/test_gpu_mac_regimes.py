@@ -30,25 +30,12 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block == 13))
 
 
-STATIC_LOOP_CASES = [   # (name, expected code 3120000 + 100*PT + {1, 2, 3 = two k-tiles with H staged through LDS} with PT = the partition count, K multiple, P multiple, capsules, events)
-    ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
-    ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
-    ("one_ktile_full6", 3120601, 10.0006, 5.002, 4, 3),        # K = 11, P = 6 = PT
-    ("one_ktile_masked6", 3120301, 6.5, 2.5, 3, 1),            # K = 7, P = 3; one event: capsule ranges split
-    ("three_ktiles_idle_half", 3121203, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles in 2 workgroups (LDS-staged H), the last has an idle half
-    ("lds_ring_odd_partitions", 3120903, 30.2, 8.6, 3, 2),     # K = 31, P = 9: the staging copy has a ragged last round
-    ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
-    ("two_units_odd", 3121303, 17.3, 12.6, 3, 2),              # P = 13: two units of 7, the 14th partition is a zero LDS row
-    ("two_units_16_long", 3121603, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
-    ("two_units_one_ktile", 3121403, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
-]
-
-
 @pytest.mark.parametrize("log2_block", [10, 13])
-@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", STATIC_LOOP_CASES, ids=[c[0] for c in STATIC_LOOP_CASES])
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.STATIC_LOOP_CASES, ids=[c[0] for c in mr.STATIC_LOOP_CASES])
 def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
-    """k_spectral_mac_static (default for one-emitter events with at most 16 partitions): every instantiation, ragged
-    tiles, the capsule-range split of small batches; every row against the oracle."""
+    """k_spectral_mac_static / _static_lds (default for one-emitter events with at most 16 partitions): EVERY instantiation
+    -- partition counts 1..16 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
+    the capsule-range split of small batches; every row against the oracle, the instantiation asserted."""
     monkeypatch.delenv("AL_STATIC_MAC", raising=False)
     monkeypatch.delenv("AL_FUSED", raising=False)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
@@ -150,6 +137,13 @@ def test_cfg3_regime_all_rows(gpu):
     every row against the oracle (the full config differs only in the event / capsule counts)."""
     res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=612, C=4, E=2)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
+
+
+def test_cfg4_regime_all_rows(gpu):
+    """cfg4's own accumulate at full length: B = 8192, K = 24, P = 6 (4 s clips, 1 s RIRs @ 48 kHz) -> k_spectral_mac_static<12,6,2>;
+    3 events x 5 capsules, every row against the oracle."""
+    res = mr.run_static_case(gpu, 13, 3120602, 192000 / 8192, 48000 / 8192, C=5, E=3, expect_fused=False, expect_split=True)
+    assert res.plan.n_partitions == 6 and int(res.plan.events["n_blocks"].max()) == 24
 
 
 def test_cfg2_regime_all_rows(gpu):

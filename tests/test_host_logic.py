@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "audiblelight_hip.h")).read()
     declared = set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
-    assert lib.call("al_abi_version") == 1
+    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 3
     assert lib.call("al_twiddle_bytes", 13) == 8 * 8192 and lib.call("al_twiddle_bytes", 9) == -1
     assert lib.call("al_row_stats_partials", 3, 40000) == 4 * 3 * 3
     assert lib.call("al_noise_workspace_floats", 2, 1000) > 0
@@ -31,12 +31,23 @@ def test_cabi_library_exports_every_declared_symbol():
     bad = _hip.AlBatch(log2_block=3, n_capsules=1, hop=128)
     with pytest.raises(_hip.HipError, match=r"log2_block must be in \[10, 14\]"):
         lib.call("al_ir_spectra", ct.byref(bad), None)
+    # a descriptor laid out for another header version (shorter struct, older ABI) is refused, not misread
+    old = _hip.AlBatch(log2_block=13, n_capsules=1, hop=128)
+    old.struct_size -= 24
+    with pytest.raises(_hip.HipError, match="another version of audiblelight_hip.h"):
+        lib.call("al_spectral_mac", ct.byref(old), None)
+    old_mix = _hip.AlMix(n_capsules=1, n_samples=8, tile=4096, n_tiles=1)
+    old_mix.abi_version = 1
+    with pytest.raises(_hip.HipError, match="another version of audiblelight_hip.h"):
+        lib.call("al_mixdown", ct.byref(old_mix), None)
 
 
 def test_struct_layouts_match_the_header():
     assert _hip.EVENT_DTYPE.itemsize == 56 and _hip.STREAM_DTYPE.itemsize == 32
-    assert ct.sizeof(_hip.AlBatch) == 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4   # 16 pointers, then the two zero-block indices
-    assert ct.sizeof(_hip.AlMix) == 6 * 4 + 13 * 8
+    assert ct.sizeof(_hip.AlBatch) == 2 * 4 + 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4   # head, ..., 16 pointers, the two zero-block indices
+    assert ct.sizeof(_hip.AlMix) == 2 * 4 + 6 * 4 + 13 * 8
+    b, m = _hip.AlBatch(log2_block=13), _hip.AlMix()
+    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (224, 3, 136, 3)
     assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
 
 
@@ -264,3 +275,25 @@ def test_planner_invariants_on_random_scenes():
         np.testing.assert_array_equal(got_cover, want_cover)
 
     check()
+
+
+def test_every_accumulate_instantiation_is_named_by_a_gpu_test():
+    """Every k_spectral_mac* kernel the library holds (nm -C) must be the expected instantiation of some -m gpu parity test
+    (tests/mac_regimes.py: STATIC_CASES, STATIC_LOOP_CASES, MOVING_CODES, EXTRA_STATIC_CODES, each asserted through
+    al_spectral_mac_variant, which reads the launcher's own descriptor): no accumulate kernel ships unpinned."""
+    import subprocess
+
+    from tests import mac_regimes as mr
+
+    out = subprocess.check_output(["nm", "-C", _hip.DEFAULT_LIB]).decode()
+    syms = {line.split(" ", 2)[2] for line in out.splitlines() if "k_spectral_mac" in line and "__device_stub__" not in line}
+    assert len(syms) >= 40                                  # 12 x {one k-tile, pair, LDS ring} + 2 two-unit + tile + moving kernels
+    asserted, unpinned = mr.asserted_codes(), []
+    for sym in sorted(syms):
+        codes = mr.codes_of_kernel_symbol(sym)
+        assert codes, f"cannot map {sym} to a variant code"
+        unpinned += [(sym, c) for c in codes if c not in asserted]
+    assert not unpinned, unpinned
+    # and the other way round: every asserted code has a kernel behind it
+    have = {c for sym in syms for c in mr.codes_of_kernel_symbol(sym)}
+    assert asserted <= have, sorted(asserted - have)

@@ -9,7 +9,7 @@ import pytest
 from audiblelight_amd import _hip, augmentation as aug, core, engine, synthesize as syn
 from oracle import synth_oracle as orc
 from tests import hostemu
-from tests.conftest import rel_rms
+from tests.conftest import pcm16, rel_rms
 
 TOL = 1e-4
 
@@ -322,17 +322,17 @@ def test_scene_generate_argument_list(golden, tmp_path):
     from scipy.io import wavfile
 
     scene = build_g8_scene(golden, with_ambience=False)
-    out = scene.generate(output_dir=str(tmp_path), audio_fname="mix.wav", metadata_fname="meta")
+    out = scene.generate(output_dir=str(tmp_path), audio_fname="mix.wav", metadata_fname="meta", metadata_dcase=False)
     sr, data = wavfile.read(str(tmp_path / "mix_mic000.wav"))
     assert sr == scene.sample_rate and data.dtype == np.int16       # soundfile's default subtype (core.py:1840-1847)
-    np.testing.assert_array_equal(data, np.clip(np.rint(out["mic000"].T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16))
-    scene.generate(output_dir=str(tmp_path), audio_fname="mixf", audio_subtype="FLOAT")
+    np.testing.assert_array_equal(data, pcm16(out["mic000"].T))
+    scene.generate(output_dir=str(tmp_path), audio_fname="mixf", audio_subtype="FLOAT", metadata_dcase=False)
     sr, data = wavfile.read(str(tmp_path / "mixf_mic000.wav"))
     assert data.dtype == np.float32
     np.testing.assert_array_equal(data.T, out["mic000"])
     assert (tmp_path / "meta.json").exists()
-    with pytest.raises(ValueError, match="DCASE"):        # events built from bare arrays carry no class index / positions
-        scene.generate(output_dir=str(tmp_path), audio=False, metadata_dcase=True)
+    with pytest.raises(ValueError, match="DCASE"):        # events built from bare arrays carry no class index / positions,
+        scene.generate(output_dir=str(tmp_path), audio=False)   # and DCASE metadata is ON by default (core.py:1794)
     with pytest.raises(NotImplementedError):
         scene.generate(video=True)
 
@@ -473,7 +473,7 @@ def test_encode_frames_every_store_path():
             assert not got[C * T:].any(), (C, T, fmt)                    # nothing past the payload
             got = got[: C * T].reshape(T, C)
             if dtype == np.int16:
-                want = np.clip(np.rint(scene.T.astype(np.float64) * 32767.0), -32768, 32767).astype(np.int16)
+                want = pcm16(scene.T)
             else:
                 want = scene.T
             np.testing.assert_array_equal(got, want, err_msg=str((C, T, fmt)))
@@ -646,3 +646,32 @@ def test_dcase_metadata_matches_the_reference_function(tmp_path):
         df = pd.read_csv(tmp_path / f"metadata_out_{m}.csv", header=None)
         np.testing.assert_array_equal(df.to_numpy(), want[m].reset_index().to_numpy())
         assert len(df) > 0 and set(df[1]) <= {e["class_id"] for e in meta["events"].values()}
+
+
+def test_one_fx_realisation_per_event_across_microphones():
+    """TimeWarp* draws its coin flips when it is applied (augmentation.py:1604-1790).  The reference's load_audio caches the
+    clip, so every microphone, the dry path and a later load_audio see ONE realisation (event.py:507-510,538); here the
+    chain runs once per event on the device and that resident clip serves them all."""
+    rng = np.random.default_rng(77)
+    sr = 8000
+    raw = rng.standard_normal(4000).astype(np.float32)
+    irs = {"mic_a": np.zeros((2, 1, 8), np.float32), "mic_b": np.zeros((3, 1, 8), np.float32)}
+    irs["mic_a"][:, 0, 0] = 1.0      # unit impulses: the render is the (scaled) clip itself
+    irs["mic_b"][:, 0, 0] = 1.0
+    scene = core.Scene(1.0, core.StaticIRState(irs), sample_rate=sr, ref_db=-65)
+    ev = scene.add_event(core.Event("e0", raw, sr, snr=10.0, scene_start=0.1,
+                                    augmentations=[aug.TimeWarpReverse(sr, fps=20, prob=0.5), aug.TimeWarpSilence(sr, fps=10, prob=0.3)]))
+    random.seed(5)
+    scene.generate()
+    chain = ev._last_chain
+    assert chain is not None and chain.uploads == 1 and chain.downloads == 0
+    a, b = ev.spatial_audio["mic_a"], ev.spatial_audio["mic_b"]
+    unit = lambda x: x / np.max(np.abs(x))  # noqa: E731
+    for row in list(a) + list(b):
+        assert rel_rms(unit(row), unit(a[0])) < 1e-5         # same clip at every capsule of both microphones
+    clip = ev.load_audio()                                    # ... and it is the clip load_audio hands out afterwards
+    assert ev._last_chain is chain and chain.downloads == 1
+    assert rel_rms(unit(a[0]), unit(clip)) < 1e-5
+    assert not np.allclose(unit(clip), unit(raw))             # the warp did something
+    ev.clear_audio()                                          # dropping the cache draws a new realisation
+    assert ev._last_chain is None

@@ -118,6 +118,11 @@ SYMBOLS = {
     "al_pack_irs_f32": (ct.c_int, [_P, _P, ct.c_int64, ct.c_int32, ct.c_int32, _S]),
     "al_noise_workspace_floats": (ct.c_int64, [ct.c_int32, ct.c_int64]),
     "al_noise_irfft": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
+    "al_noise_irfft_seeded": (ct.c_int, [ct.c_uint64, _P, ct.c_int32, ct.c_int64, ct.c_float, _P, _P, _S]),
+    "al_normal_fill": (ct.c_int, [_P, ct.c_int64, ct.c_uint64, ct.c_uint32, ct.c_float, _S]),
+    "al_philox4x32_10": (ct.c_int, [ct.POINTER(ct.c_uint32), ct.POINTER(ct.c_uint32), ct.POINTER(ct.c_uint32)]),
+    "al_ambience_scales": (ct.c_int, [_P, ct.c_int32, ct.c_int64, ct.c_float, ct.c_int32, _P, _S]),
+    "al_axpy_rows": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int64, _S]),
     "al_stft_workspace_floats": (ct.c_int64, [ct.c_int64, ct.c_int32]),
     "al_stft": (ct.c_int, [_P, ct.c_int64, ct.c_int64, ct.c_int32, ct.c_int32, ct.c_int32, _P, _P, _S]),
     "al_tv_stft_mac": (ct.c_int, [_P, _P, _P, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32, _P, _S]),

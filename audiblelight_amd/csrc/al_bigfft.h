@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "al_fft.h"
+#include "al_rng.h"
 
 namespace al {
 
@@ -64,9 +65,21 @@ __global__ __launch_bounds__(256) void k_big_pass(const float2 *__restrict__ in,
 // written as the input of the complex inverse transform.
 //   even n (m = n/2): Z[k] = E + iO,  E = (S[k] + conj S[m-k])/2,  O = (S[k] - conj S[m-k])/2 * e^{+2 pi i k/n}
 //   odd n: the Hermitian extension full[k], k < n.
-__device__ __forceinline__ float2 noise_bin(const float *zr, const float *zi, const float *shape, int64_t f, int64_t n) {
-  const float s = shape[f];
-  float re = zr[f] * s, im = zi[f] * s;
+// Where the standard-normal draws of a spectrum row come from: arrays the host filled (numpy's default_rng: bit-identical
+// to the reference for a seed) or the device generator of al_rng.h (zr == nullptr).
+struct NoiseDraws {
+  const float *zr, *zi;   // this row's draws (host mode)
+  uint64_t seed;          // device mode
+  int64_t row, bins;
+  __device__ __forceinline__ float2 at(int64_t f) const {
+    return zr ? make_float2(zr[f], zi[f]) : spectrum_draw(seed, row, bins, f);
+  }
+};
+
+__device__ __forceinline__ float2 noise_bin(const NoiseDraws &d, const float *shape, int64_t f, int64_t n) {
+  const float s = shape ? shape[f] : 1.0f;
+  const float2 z = d.at(f);
+  float re = z.x * s, im = z.y * s;
   if (f == 0 || (2 * f == n)) {
     im = 0.f;
     re *= 1.41421356237309504880f;
@@ -74,22 +87,23 @@ __device__ __forceinline__ float2 noise_bin(const float *zr, const float *zi, co
   return make_float2(re, im);
 }
 
-__global__ __launch_bounds__(256) void k_noise_pack(const float *zr, const float *zi, const float *shape, int64_t n,
+__global__ __launch_bounds__(256) void k_noise_pack(const float *zr, const float *zi, uint64_t seed, const float *shape, int64_t n,
                                                     float2 *z) {
   const int64_t bins = n / 2 + 1;
-  const float *r0 = zr + (int64_t)blockIdx.y * bins, *i0 = zi + (int64_t)blockIdx.y * bins;
+  const NoiseDraws d{zr ? zr + (int64_t)blockIdx.y * bins : nullptr, zi ? zi + (int64_t)blockIdx.y * bins : nullptr, seed,
+                     (int64_t)blockIdx.y, bins};
   const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if ((n & 1) == 0) {
     const int64_t m = n / 2;
     if (k >= m) return;
-    const float2 a = noise_bin(r0, i0, shape, k, n), b = noise_bin(r0, i0, shape, m - k, n);
+    const float2 a = noise_bin(d, shape, k, n), b = noise_bin(d, shape, m - k, n);
     const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-    const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
-    const float2 o = cmul(d, unit_phase((double)k / (double)n));
+    const float2 dd = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+    const float2 o = cmul(dd, unit_phase((double)k / (double)n));
     z[(int64_t)blockIdx.y * m + k] = make_float2(e.x - o.y, e.y + o.x);
   } else {
     if (k >= n) return;
-    const float2 a = k <= n / 2 ? noise_bin(r0, i0, shape, k, n) : cconj(noise_bin(r0, i0, shape, n - k, n));
+    const float2 a = k <= n / 2 ? noise_bin(d, shape, k, n) : cconj(noise_bin(d, shape, n - k, n));
     z[(int64_t)blockIdx.y * n + k] = a;
   }
 }

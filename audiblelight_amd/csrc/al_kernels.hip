@@ -579,7 +579,7 @@ __global__ __launch_bounds__(256) void k_mixdown(al_mix m) {
   constexpr int RUNS = 4;                       // m.tile == 4 * 256 * RUNS
   float4 acc[RUNS];
   const bool whole = (t_begin + m.tile <= m.n_samples) && ((m.n_samples & 3) == 0);  // workgroup-uniform
-  const float amb_scale = m.ambience ? *m.ambience_scale : 0.f;
+  const float amb_scale = m.ambience ? m.ambience_scale[c] : 0.f;   // per capsule: peak normalisation x noise-floor multiplier
   const float *amb = m.ambience ? m.ambience + (int64_t)c * m.n_samples : row;
 #pragma unroll
   for (int r = 0; r < RUNS; ++r) {
@@ -654,6 +654,38 @@ __global__ __launch_bounds__(256) void k_axpy(float *y, const float *x, const fl
   const float s = *a;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     y[i] = fmaf(s, x[i], y[i]);
+}
+
+// y[r, :] += a[r] * x[r, :]: an ambience with its per-channel scale (second and further ambiences of a scene)
+__global__ __launch_bounds__(256) void k_axpy_rows(float *y, const float *x, const float *a, int64_t cols) {
+  const float s = a[blockIdx.y];
+  const int64_t base = (int64_t)blockIdx.y * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < cols; i += (int64_t)gridDim.x * 256)
+    y[base + i] = fmaf(s, x[base + i], y[base + i]);
+}
+
+// Per-channel multiplier of an ambience from its row statistics {sum|x|, max|x|, ...} (al_row_stats), one wave, float64:
+// the per-channel peak normalisation ch / max(|ch| + tiny) (ambience.py:211-214) and db_to_multiplier(ref_db, mean|normalised|)
+// (synthesize.py:350-356) as ONE scalar per channel, so the noise is neither rescaled in place nor read by the host.
+__global__ __launch_bounds__(64) void k_ambience_scales(const double *__restrict__ stats, int rows, int64_t cols, float ref_db,
+                                                        int normalize, float *__restrict__ scales) {
+  const int lane = threadIdx.x;
+  double acc = 0.0;
+  for (int c = lane; c < rows; c += 64) {
+    const double inv = normalize ? 1.0 / (stats[4 * c + 1] + 2.2250738585072014e-308) : 1.0;
+    acc += stats[4 * c] * inv;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  __shared__ double total;
+  if (lane == 0) total = acc;
+  __syncthreads();
+  const double mean_abs = total / ((double)rows * (double)cols);
+  const double mult = pow(10.0, (double)ref_db / 20.0) / (mean_abs + 2.2250738585072014e-308);
+  for (int c = lane; c < rows; c += 64) {
+    const double inv = normalize ? 1.0 / (stats[4 * c + 1] + 2.2250738585072014e-308) : 1.0;
+    scales[c] = (float)(normalize == 2 ? inv : mult * inv);   // 2: the peak normalisation alone
+  }
 }
 
 constexpr int ROW_CHUNK = 16384;  // samples per partial of k_row_stats
@@ -1418,10 +1450,10 @@ int64_t al_noise_workspace_floats(int32_t rows, int64_t n) {
   return 2 * (2 * (int64_t)rows * per) + (p.bluestein ? 2 * 2 * p.L + 2 * (int64_t)rows * p.len : 0);
 }
 
-int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t rows, int64_t n, float inv_sigma,
-                   float *out, float *workspace, al_stream_t stream) {
-  if (!zr || !zi || !shape || !out || !workspace || rows <= 0 || n <= 0) return fail(AL_E_BADARG, "bad noise arguments");
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+// irfft of rows x (n/2+1) shaped draws; zr == nullptr: the draws come from the device generator under `seed`
+int noise_irfft(const float *zr, const float *zi, uint64_t seed, const float *shape, int32_t rows, int64_t n, float inv_sigma,
+                float *out, float *workspace, hipStream_t st) {
   const BigPlan p = big_plan(n);
   const int64_t per = p.bluestein ? p.L : p.len;
   float2 *a = reinterpret_cast<float2 *>(workspace);
@@ -1429,13 +1461,13 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
   const dim3 g_len((unsigned)((p.len + 255) / 256), rows);
   const float2 *z;
   if (!p.bluestein) {
-    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, shape, n, a);
+    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, seed, shape, n, a);
     z = big_fft(a, b, rows, p.len, +1, st);
   } else {
     float2 *kern = b + (int64_t)rows * per;           // 2 * L: chirp kernel and its ping-pong partner
     float2 *x = kern + 2 * p.L;                        // rows * len: packed spectrum / transform result
     const dim3 g_L((unsigned)((p.L + 255) / 256), rows), g_L1((unsigned)((p.L + 255) / 256), 1);
-    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, shape, n, x);
+    hipLaunchKernelGGL(al::k_noise_pack, g_len, dim3(256), 0, st, zr, zi, seed, shape, n, x);
     hipLaunchKernelGGL(al::k_blue_kernel, g_L1, dim3(256), 0, st, p.len, p.L, +1, kern);
     const float2 *kspec = big_fft(kern, kern + p.L, 1, p.L, -1, st);
     hipLaunchKernelGGL(al::k_blue_pre, g_L, dim3(256), 0, st, (const float2 *)x, p.len, p.L, +1, a);
@@ -1448,6 +1480,50 @@ int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t
   }
   hipLaunchKernelGGL(al::k_noise_unpack, g_len, dim3(256), 0, st, z, n, inv_sigma / (float)p.len, out);
   return check_launch("al_noise_irfft");  // hipGetLastError keeps the first failure of the sequence until it is read
+}
+}  // namespace
+
+int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t rows, int64_t n, float inv_sigma,
+                   float *out, float *workspace, al_stream_t stream) {
+  if (!zr || !zi || !shape || !out || !workspace || rows <= 0 || n <= 0) return fail(AL_E_BADARG, "bad noise arguments");
+  return noise_irfft(zr, zi, 0, shape, rows, n, inv_sigma, out, workspace, (hipStream_t)stream);
+}
+
+int al_noise_irfft_seeded(uint64_t seed, const float *shape, int32_t rows, int64_t n, float inv_sigma, float *out,
+                          float *workspace, al_stream_t stream) {
+  if (!out || !workspace || rows <= 0 || n <= 0) return fail(AL_E_BADARG, "bad noise arguments");
+  return noise_irfft(nullptr, nullptr, seed, shape, rows, n, inv_sigma, out, workspace, (hipStream_t)stream);
+}
+
+int al_normal_fill(float *out, int64_t n, uint64_t seed, uint32_t tag, float scale, al_stream_t stream) {
+  if (!out || n <= 0) return fail(AL_E_BADARG, "bad normal_fill arguments");
+  if (((uintptr_t)out & 15) != 0) return fail(AL_E_BADARG, "normal_fill: output must be 16-byte aligned");
+  const int64_t blocks = (n / 4 + 256) / 256;
+  hipLaunchKernelGGL(al::k_normal_fill, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, (hipStream_t)stream, out, n,
+                     seed, tag, scale);
+  return check_launch("k_normal_fill");
+}
+
+int al_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+  if (!counter || !key || !out) return fail(AL_E_BADARG, "bad philox arguments");
+  const al::Philox4 p = al::philox4x32_10(counter[0], counter[1], counter[2], counter[3], key[0], key[1]);
+  out[0] = p.x; out[1] = p.y; out[2] = p.z; out[3] = p.w;
+  return AL_OK;
+}
+
+int al_ambience_scales(const double *row_stats, int32_t rows, int64_t cols, float ref_db, int32_t normalize, float *scales,
+                       al_stream_t stream) {
+  if (!row_stats || !scales || rows <= 0 || rows > 1024 || cols <= 0) return fail(AL_E_BADARG, "bad ambience_scales arguments");
+  hipLaunchKernelGGL(al::k_ambience_scales, dim3(1), dim3(64), 0, (hipStream_t)stream, row_stats, rows, cols, ref_db, normalize, scales);
+  return check_launch("k_ambience_scales");
+}
+
+int al_axpy_rows(float *y, const float *x, const float *a_dev, int32_t rows, int64_t cols, al_stream_t stream) {
+  if (!x || !y || !a_dev || rows <= 0 || rows > 65535 || cols <= 0) return fail(AL_E_BADARG, "bad axpy_rows arguments");
+  const int64_t blocks = (cols + 255) / 256;
+  hipLaunchKernelGGL(al::k_axpy_rows, dim3((unsigned)(blocks < 2048 ? blocks : 2048), rows), dim3(256), 0, (hipStream_t)stream, y, x,
+                     a_dev, cols);
+  return check_launch("k_axpy_rows");
 }
 
 // ---- STFT-domain intermediates of the moving path (A7), reference signatures kept in audiblelight_amd/synthesize.py

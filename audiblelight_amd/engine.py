@@ -398,7 +398,7 @@ class Renderer:
 
     # -- A11
     def mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = ()):
-        """scene (C, T) float32 on device.  ``ambience`` = [(device noise (C*T floats), device scalar)]."""
+        """scene (C, T) float32 on device.  ``ambience`` = [(device noise (C*T floats), device float32[C] multipliers)]."""
         return self.prepare_mixdown(mix, result, ambience).run()
 
     def row_stats(self, x_dev, rows: int, cols: int):
@@ -526,6 +526,7 @@ class PreparedMix:
             if self.zero_first:
                 self.scene.zero_() if hasattr(self.scene, "zero_") else self.scene.fill(0)
             for noise, a_dev in self.ambience:
-                lib.call("al_axpy", mem.ptr(self.scene), mem.ptr(noise), mem.ptr(a_dev), n, stream)
+                lib.call("al_axpy_rows", mem.ptr(self.scene), mem.ptr(noise), mem.ptr(a_dev), self.mix.n_capsules,
+                         self.mix.n_samples, stream)
         lib.call("al_mixdown", ct.byref(self.desc), stream)
         return self.scene

@@ -432,7 +432,13 @@ def encode_scene_frames(scene, mic_alias: str, subtype: str = "PCM_16") -> np.nd
 
 
 def _ambience_on_device(r: engine.Renderer, ambience, shape):
-    """(device noise, device scalar): load_ambience(normalize=True) x db_to_multiplier(ref_db, mean|noise|)."""
+    """(device noise, device float32[channels] of per-channel multipliers): load_ambience(normalize=True) x
+    db_to_multiplier(ref_db, mean|noise|) (synthesize.py:350-356).  Device-drawn ambiences never meet the host: the noise
+    stays un-normalised and the peak normalisation rides in the per-channel multiplier (Ambience.noise_and_scales_device)."""
+    if hasattr(ambience, "noise_and_scales_device"):
+        pair = ambience.noise_and_scales_device(r, shape)
+        if pair is not None:
+            return pair
     dev = ambience.load_ambience_device(r) if hasattr(ambience, "load_ambience_device") else None
     if dev is None:
         host = np.asarray(ambience.load_ambience(normalize=True))
@@ -449,7 +455,7 @@ def _ambience_on_device(r: engine.Renderer, ambience, shape):
     n = shape[0] * shape[1]
     stats = r.mem.download(r.row_stats(dev, 1, n)).reshape(-1, 4)
     mult = db_to_multiplier(ambience.ref_db, stats[0, 0] / n)
-    return dev, r.mem.upload(np.array([mult], dtype=np.float32))
+    return dev, r.mem.upload(np.full(shape[0], mult, dtype=np.float32))
 
 
 def _attach_padded(events, idxs, mix, mic_alias, channels, duration) -> None:

@@ -166,9 +166,11 @@ typedef struct {
   const float *spatial;
   const float *event_scale;
   float *scene;             /* (C, n_samples) float32 */
-  const float *ambience;       /* optional (NULL = none): (C, n_samples) normalised noise, added as *ambience_scale * noise */
-  const float *ambience_scale; /* in the same pass that mixes the events (synthesize.py:350-356 fused with :358-383): the */
-                               /* scene is written once instead of zeroed, read-modify-written, and read-modify-written again */
+  const float *ambience;       /* optional (NULL = none): (C, n_samples) noise, added as ambience_scale[c] * noise[c] in the */
+  const float *ambience_scale; /* same pass that mixes the events (synthesize.py:350-356 fused with :358-383): the scene is */
+                               /* written once instead of zeroed and read-modify-written twice.  n_capsules floats: the */
+                               /* noise-floor multiplier, times 1/peak of the channel when the noise is handed over */
+                               /* un-normalised (al_ambience_scales) */
 } al_mix;
 
 const char *al_last_error(void);
@@ -265,6 +267,24 @@ int64_t al_noise_workspace_floats(int32_t rows, int64_t n);
 /* out[r, :] = irfft((zr + i zi) * shape)[r] / sigma ; zr, zi: (rows, n/2+1) float32 draws; shape: n/2+1 float32. */
 int al_noise_irfft(const float *zr, const float *zi, const float *shape, int32_t rows, int64_t n, float inv_sigma,
                    float *out, float *workspace, al_stream_t stream);
+/* The same with the draws made ON THE DEVICE (csrc/al_rng.h: Philox-4x32-10 counters + Box-Muller; (zr, zi) of bin f of row r
+ * is a pure function of (seed, r, f)): nothing is drawn, cast or uploaded by the host.  The realisation differs from numpy's
+ * for the same seed -- the reference's own tests of this function are statistical (tests/test_ambience.py:30-67) plus
+ * fixed-seed reproducibility (:70-76), which this keeps.  shape == NULL: flat (white). */
+int al_noise_irfft_seeded(uint64_t seed, const float *shape, int32_t rows, int64_t n, float inv_sigma, float *out,
+                          float *workspace, al_stream_t stream);
+/* out[i] = scale * N(0,1) for i < n, element i = normal (i % 4) of Philox counter block i / 4 under (seed, tag): "gaussian"
+ * ambience (ambience.py:160-165) and white noise, whose Timmer-Koenig synthesis is iid Gaussian in time (flat spectrum). */
+int al_normal_fill(float *out, int64_t n, uint64_t seed, uint32_t tag, float scale, al_stream_t stream);
+/* Philox-4x32-10 on the HOST (the same function the kernels call), for known-answer tests: all arguments host pointers. */
+int al_philox4x32_10(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* scales[c] = db_to_multiplier(ref_db, mean|normalised noise|) / (normalize ? max|noise_c| + tiny : 1) from al_row_stats'
+ * output, on the device (ambience.py:211-214 + synthesize.py:350-356 as one scalar per channel; rows <= 1024).
+ * normalize == 2: scales[c] = 1 / (max|noise_c| + tiny) alone (Ambience.load_ambience(normalize=True) without the floor). */
+int al_ambience_scales(const double *row_stats, int32_t rows, int64_t cols, float ref_db, int32_t normalize, float *scales,
+                       al_stream_t stream);
+/* y[r, :] += a_dev[r] * x[r, :] over a (rows, cols) matrix: second and further ambiences of a scene. */
+int al_axpy_rows(float *y, const float *x, const float *a_dev, int32_t rows, int64_t cols, al_stream_t stream);
 /* x[r, :] *= scale[r]: per-channel peak normalisation (ambience.py:211-214) after al_row_stats. */
 int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scale, al_stream_t stream);
 

@@ -486,3 +486,18 @@ def fx_timewarp(a, sr, fps, decisions, mode):
         elif mode == "reverse":
             rows.append(row[::-1] if hit else row)
     return np.concatenate(rows) if rows else a
+
+
+# --------------------------------------------------------------------------- device generator witness (no reference counterpart)
+def philox4x32_10(counter, key):
+    """Philox-4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11), plain Python
+    integers: the counter-based generator the device ambience draws from (audiblelight_amd/csrc/al_rng.h).  The reference
+    itself draws with numpy's PCG64 (ambience.py:351-356), which has no parallel form; this restatement exists so the tests
+    can hold the kernel's draws to an independent implementation (and both to the Random123 known-answer vectors)."""
+    c0, c1, c2, c3 = (int(x) & 0xFFFFFFFF for x in counter)
+    k0, k1 = (int(x) & 0xFFFFFFFF for x in key)
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = (p1 >> 32) ^ c1 ^ k0, p1 & 0xFFFFFFFF, (p0 >> 32) ^ c3 ^ k1, p0 & 0xFFFFFFFF
+        k0, k1 = (k0 + 0x9E3779B9) & 0xFFFFFFFF, (k1 + 0xBB67AE85) & 0xFFFFFFFF
+    return c0, c1, c2, c3

@@ -109,6 +109,10 @@ static inline void sincospi(double x, double *s, double *c) {
   *c = cos(M_PI * x);
 }
 static inline float sinpif(float x) { return (float)sin(M_PI * (double)x); }
+static inline void sincospif(float x, float *s, float *c) {
+  *s = (float)sin(M_PI * (double)x);
+  *c = (float)cos(M_PI * (double)x);
+}
 static inline unsigned __float_as_uint(float x) { unsigned u; memcpy(&u, &x, 4); return u; }
 using std::isfinite;
 using std::max;

@@ -90,7 +90,7 @@ def test_full_scene_golden(gpu, planning, golden):
     stats = gpu.mem.download(gpu.row_stats(amb_dev, 1, amb.size)).reshape(-1, 4)
     assert stats[0, 0] == pytest.approx(np.abs(amb.astype(np.float64)).sum(), rel=1e-6)
     mult = np.float32(orc.db_gain(-65, stats[0, 0] / amb.size))
-    scene = gpu.mem.download(gpu.mixdown(mix, res, [(amb_dev, gpu.mem.upload(np.array([mult], np.float32)))]))
+    scene = gpu.mem.download(gpu.mixdown(mix, res, [(amb_dev, gpu.mem.upload(np.full(mix.n_capsules, mult, np.float32)))]))
     assert_close(scene[: C * mix.n_samples].reshape(C, -1), golden["g8_scene"])
 
 

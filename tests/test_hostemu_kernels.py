@@ -150,7 +150,7 @@ def test_emu_full_scene_with_ambience(emu, golden):
     assert stats[0, 0] == pytest.approx(np.abs(amb.astype(np.float64)).sum(), rel=1e-6)
     assert stats[0, 1] == pytest.approx(np.abs(amb).max())
     mult = np.float32(orc.db_gain(-65, stats[0, 0] / amb.size))
-    scene = emu.mem.download(emu.mixdown(mix, res, ambience=[(amb_dev, emu.mem.upload(np.array([mult], np.float32)))]))
+    scene = emu.mem.download(emu.mixdown(mix, res, ambience=[(amb_dev, emu.mem.upload(np.full(mix.n_capsules, mult, np.float32)))]))
     scene = scene[: C * mix.n_samples].reshape(C, mix.n_samples)
     assert rel_rms(scene, golden["g8_scene"]) < TOL
     # without ambience: plain overwrite path

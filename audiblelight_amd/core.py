@@ -56,8 +56,8 @@ class Event:
         self.audio: Optional[np.ndarray] = None
         self.spatial_audio = LazyAudioDict()
         self._spatial_audio_padded = LazyAudioDict()
-        self._spatial_audio_dry: Dict[str, np.ndarray] = OrderedDict()
-        self._spatial_audio_dry_padded: Dict[str, np.ndarray] = OrderedDict()
+        self._spatial_audio_dry = LazyAudioDict()
+        self._spatial_audio_dry_padded = LazyAudioDict()
 
     def __len__(self) -> int:
         return self.n_emitters
@@ -90,8 +90,8 @@ class Event:
         self._last_chain = None
         self.spatial_audio = LazyAudioDict()
         self._spatial_audio_padded = LazyAudioDict()
-        self._spatial_audio_dry = OrderedDict()
-        self._spatial_audio_dry_padded = OrderedDict()
+        self._spatial_audio_dry = LazyAudioDict()
+        self._spatial_audio_dry_padded = LazyAudioDict()
 
     def _device_chain(self, normalize: bool, staged=None):
         """Raw clip -> HBM once, the whole FX chain (and, if asked, the peak normalisation) there (augmentation.run_chain).

@@ -130,18 +130,9 @@ def capsule_slice(n_capsules: int, rank: int, world_size: int) -> slice:
     return slice(lo, lo + base + (1 if rank < rem else 0))
 
 
-def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_capsules: int, sample_rate: float,
-                           log2_block: Optional[int] = None):
-    """Render one microphone of one scene with this rank's capsules only.
-
-    Every rank convolves all events against its own capsule rows of the IR tensor (clips are replicated: small).
-    The per-event level (one scalar from sum|x| and max|x| over ALL capsules, synthesize.py:594-599) is the
-    only coupling: one all-reduce of E x {SUM, MAX, SUM} doubles between block synthesis and the level law.
-    Returns the RenderResult of the local capsules (event_scale identical on every rank).
-    """
-    import ctypes as ct
-
-    import torch
+def prepare_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_capsules: int, sample_rate: float,
+                            log2_block: Optional[int] = None):
+    """Upload this rank's capsule rows + the (replicated) clips and allocate the workspaces of ``run_capsule_sharded``."""
     import torch.distributed as dist
 
     from . import plan as planning
@@ -152,7 +143,18 @@ def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_
     if irs_local.shape[0] == 0:
         raise ValueError("this rank owns no capsule rows")
     pl = planning.plan_batch(specs, irs_local.shape[0], irs_local.shape[2], sample_rate, log2_block=log2_block)
-    batch = renderer.prepare(pl, clips, irs_local)
+    return renderer.prepare(pl, clips, irs_local)
+
+
+def run_capsule_sharded(renderer, batch, total_capsules: int, timers: Optional[dict] = None):
+    """One pass of a prepared capsule-sharded batch: only enqueues (kernels and two stream-ordered collectives on DEVICE
+    arrays; nothing is copied to the host and nothing waits).  ``timers``: a dict that receives ``(start, end)`` event
+    pairs around each collective (``make_event()`` from the caller under key "make_event"), for bench.py."""
+    import ctypes as ct
+
+    import torch
+    import torch.distributed as dist
+
     lib, stream = renderer.lib, renderer.mem.stream()
     desc = batch.descs[0]
     sharded = dist.is_initialized() and dist.get_world_size() > 1
@@ -160,21 +162,46 @@ def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_
     def as_tensor(buf):   # device tensors as they are; host-emulated memory (CPU tests) through a torch view
         return torch.from_numpy(buf) if isinstance(buf, np.ndarray) else buf
 
-    # Both exchanges are stream-ordered collectives on device arrays: nothing is copied to the host and nothing waits.
+    def timed(key, fn):
+        if timers is None:
+            return fn()
+        a, b = timers["make_event"](), timers["make_event"]()
+        a.record()
+        fn()
+        b.record()
+        timers.setdefault(key, []).append((a, b))
+
     # 1. emitter gains are a mean over ALL capsules (normalize_irs, synthesize.py:404-428): all-reduce the norm sums
     lib.call("al_ir_spectra", ct.byref(desc), stream)
     lib.call("al_emitter_norm_sums", ct.byref(desc), stream)
     if sharded:
-        dist.all_reduce(as_tensor(batch.bufs["emitter_gain"]), op=dist.ReduceOp.SUM)
+        timed("allreduce_ir_norms", lambda: dist.all_reduce(as_tensor(batch.bufs["emitter_gain"]), op=dist.ReduceOp.SUM))
     lib.call("al_emitter_gains_from_sums", ct.byref(desc), int(total_capsules), stream)
     for name in ("al_signal_spectra", "al_spectral_mac", "al_block_synthesis", "al_event_stats"):
         lib.call(name, ct.byref(desc), stream)
     # 2. per-event level statistics {sum|x|, max|x|, non-finite count} over all capsules (synthesize.py:594-599)
     if sharded:
-        t = as_tensor(batch.bufs["event_stats"]).view(-1, 4)
-        sums, peak = t[:, [0, 2]].contiguous(), t[:, 1].contiguous()
-        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
-        dist.all_reduce(peak, op=dist.ReduceOp.MAX)
-        t[:, 0], t[:, 2], t[:, 1] = sums[:, 0], sums[:, 1], peak
+        def exchange():
+            t = as_tensor(batch.bufs["event_stats"]).view(-1, 4)
+            sums, peak = t[:, [0, 2]].contiguous(), t[:, 1].contiguous()
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+            dist.all_reduce(peak, op=dist.ReduceOp.MAX)
+            t[:, 0], t[:, 2], t[:, 1] = sums[:, 0], sums[:, 1], peak
+
+        timed("allreduce_event_levels", exchange)
     lib.call("al_event_levels_from_stats", ct.byref(desc), int(total_capsules), stream)
     return batch.result()
+
+
+def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_capsules: int, sample_rate: float,
+                           log2_block: Optional[int] = None):
+    """Render one microphone of one scene with this rank's capsules only.
+
+    Every rank convolves all events against its own capsule rows of the IR tensor (clips are replicated: small).
+    The per-event level (one scalar from sum|x| and max|x| over ALL capsules, synthesize.py:594-599) is the
+    only coupling: one all-reduce of E x {SUM, MAX, SUM} doubles between block synthesis and the level law
+    (plus the per-emitter IR norm sums of normalize_irs, synthesize.py:404-428, before the accumulate).
+    Returns the RenderResult of the local capsules (event_scale identical on every rank).
+    """
+    batch = prepare_capsule_sharded(renderer, specs, clips, irs_local, total_capsules, sample_rate, log2_block)
+    return run_capsule_sharded(renderer, batch, total_capsules)

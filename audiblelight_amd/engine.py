@@ -49,24 +49,60 @@ class TorchMemory:
             arr = arr.view(np.uint8)
         return self.torch.from_numpy(arr).to(self.device, non_blocking=False)
 
-    def upload_staged(self, n: int, fill) -> object:
+    def upload_tables(self, arrays) -> list:
+        """Several small host tables (structured or plain ndarrays) -> HBM through ONE page-locked arena and ONE asynchronous
+        DMA; returns one device tensor per table (uint8 views for structured dtypes), each 16-byte aligned.  A scene needs a
+        dozen of them (event / stream / mixdown tables): as separate pageable copies each one is a blocking round trip."""
+        flat = []
+        for a in arrays:
+            a = np.ascontiguousarray(a)
+            if a.dtype.fields is not None:
+                a = a.view(np.uint8)
+            flat.append(a.reshape(-1))
+        offs, total = [], 0
+        for a in flat:
+            offs.append(total)
+            total += (max(a.nbytes, 1) + 15) // 16 * 16
+
+        def fill(view):
+            raw = view.view(np.uint8)
+            for off, a in zip(offs, flat):
+                raw[off: off + a.nbytes] = a.view(np.uint8)
+
+        dev = self.upload_staged((total + 3) // 4, fill, tag="tables").view(self.torch.uint8)
+        out = []
+        for off, a in zip(offs, flat):
+            piece = dev[off: off + max(a.nbytes, 1)]
+            out.append(piece if a.dtype == np.uint8 else piece[: a.nbytes].view(getattr(self.torch, a.dtype.name)))
+        return out
+
+    def download_async(self, buf):
+        """Enqueue the D2H copy of a device buffer into page-locked memory on the current stream and return the host TENSOR
+        at once; it holds the data only after the stream has been synchronised (the caller batches several of these behind
+        one synchronisation)."""
+        host = self.torch.empty(buf.shape, dtype=buf.dtype, pin_memory=True)
+        host.copy_(buf, non_blocking=True)
+        return host
+
+    def upload_staged(self, n: int, fill, tag: str = "audio") -> object:
         """float32[n] assembled by ``fill(host_view)`` in a REUSED page-locked staging buffer, then one asynchronous DMA:
         for inputs that have to be packed on the host anyway (the clips of a scene).  A fresh pageable buffer would cost
-        a page fault per 4 KiB before the copy even starts."""
-        if not hasattr(self, "_staging"):
-            self._staging = [None, None]         # [page-locked buffer that only grows, event of the last DMA out of it]
-        host, last = self._staging
+        a page fault per 4 KiB before the copy even starts.  One buffer per ``tag``."""
+        if not hasattr(self, "_staging_by_tag"):
+            self._staging_by_tag = {}
+        slot = self._staging_by_tag.setdefault(tag, [None, None])   # [page-locked buffer that only grows, event of the last DMA out of it]
+        host, last = slot
         if last is not None:
             last.synchronize()                   # the previous DMA out of this buffer must have finished
         if host is None or host.numel() < n:     # page-locking costs tens of ms: grow by at least a quarter, never per size
             cap = max(int(n), 0 if host is None else host.numel() * 5 // 4)
-            host = self._staging[0] = self.torch.empty((cap + 65535) // 65536 * 65536, dtype=self.torch.float32, pin_memory=True)
+            host = slot[0] = self.torch.empty((cap + 65535) // 65536 * 65536, dtype=self.torch.float32, pin_memory=True)
         view = host[: int(n)]
         fill(view.numpy())
         dev = view.to(self.device, non_blocking=True)
         ev = self.torch.cuda.Event()
         ev.record(self.torch.cuda.current_stream(self.device))
-        self._staging[1] = ev
+        slot[1] = ev
         return dev
 
     def upload_f64_as_f32(self, arr: np.ndarray, threads: Optional[int] = None):
@@ -141,6 +177,9 @@ class TorchMemory:
         self.torch.cuda.synchronize(self.device)
 
 
+_PACK_POOL = None
+
+
 # ----------------------------------------------------------------------------- clip hand-over
 @dataclass
 class ClipSource:
@@ -182,10 +221,15 @@ class RenderResult:
     def stats(self) -> np.ndarray:
         return self.memory.download(self.event_stats)[: 4 * len(self.plan.events)].reshape(-1, 4)
 
-    def check_finite(self) -> None:
-        bad = np.flatnonzero(self.stats()[:, 2] > 0)
+    def check_finite(self, stats: Optional[np.ndarray] = None) -> None:
+        """librosa.util.valid_audio of every event's render (synthesize.py:603) from the device's non-finite counts.
+        ``stats``: the (E, 4) statistics already on the host (a caller that downloaded them with other results)."""
+        if getattr(self, "_finite_ok", False):
+            return
+        bad = np.flatnonzero((self.stats() if stats is None else stats)[:, 2] > 0)
         if len(bad):
             raise ValueError(f"Audio buffer is not finite everywhere (events {bad.tolist()})")
+        self._finite_ok = True
 
     def raw_spatial(self, i: int) -> np.ndarray:
         ev = self.plan.events[i]
@@ -255,10 +299,24 @@ class Renderer:
     def pack_audio(self, plan: BatchPlan, clips: Sequence, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Host clips at their 4-float aligned offsets (device-resident clips are copied in HBM by ``prepare``)."""
         host = np.zeros(plan.audio_floats, dtype=np.float32) if out is None else out
-        for off, clip in zip(plan.audio_offsets, clips):
-            src = as_clip_source(clip)
-            if src.host is not None:
-                host[off: off + len(src)] = src.host
+        todo = [(int(off), as_clip_source(clip).host) for off, clip in zip(plan.audio_offsets, clips)
+                if as_clip_source(clip).host is not None]
+        if sum(len(a) for _, a in todo) < (1 << 22):
+            for off, a in todo:
+                host[off: off + len(a)] = a
+            return host
+        # tens of megabytes of clips (cfg2: 49 MB): a few threads (numpy releases the GIL while it copies) instead of one
+        global _PACK_POOL
+        if _PACK_POOL is None:
+            from concurrent.futures import ThreadPoolExecutor
+
+            _PACK_POOL = ThreadPoolExecutor(4)
+
+        def put(item):
+            off, a = item
+            host[off: off + len(a)] = a
+
+        list(_PACK_POOL.map(put, todo))
         return host
 
     def auto_chunk_events(self, plan: BatchPlan) -> Optional[int]:
@@ -308,11 +366,13 @@ class Renderer:
                 if src.host is None:
                     audio_dev[int(off): int(off) + len(src)] = src.device[: len(src)]
         fold = any(src.normalize or src.prescale != 1.0 for src in sources)
+        tables = [plan.events, plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE), plan.wtab]
+        if fold:
+            tables += [np.array([src.prescale for src in sources], dtype=np.float32),
+                       np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
+        tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]
         bufs = dict(
-            audio=audio_dev, ir=irs,
-            events=mem.upload(plan.events),
-            streams=mem.upload(plan.streams if len(plan.streams) else np.zeros(1, dtype=_hip.STREAM_DTYPE)),
-            wtab=mem.upload(plan.wtab), twiddle=self.twiddle(plan.log2_block),
+            audio=audio_dev, ir=irs, events=tabs[0], streams=tabs[1], wtab=tabs[2], twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
             # one extra, all-zero block behind each spectra workspace: al_mac_synthesis reads out-of-range blocks from it
             hspec=mem.empty((h_blocks + 1) * B * 2), xspec=mem.empty((x_blocks + 1) * B * 2),
@@ -362,8 +422,7 @@ class Renderer:
                     if not (ev["n_streams"] > 1).any():
                         desc.flags |= _hip.FLAG_ONLY_STATIC
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
-            pre = mem.upload(np.array([src.prescale for src in sources], dtype=np.float32))
-            mode = mem.upload(np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32))
+            pre, mode = tabs[3], tabs[4]
             for desc in descs:
                 self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
             bufs["_clip_tables"] = (pre, mode)
@@ -379,8 +438,9 @@ class Renderer:
         """``scene``: an existing (C*T) device buffer to accumulate into (else a new buffer is made)."""
         mem = self.mem
         n = mix.n_capsules * mix.n_samples
-        tabs = [mem.upload(x) for x in (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start,
-                                        mix.slot_count, mix.slot_rows, mix.slot_event)]
+        host_tabs = (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start, mix.slot_count, mix.slot_rows,
+                     mix.slot_event)
+        tabs = mem.upload_tables(host_tabs) if hasattr(mem, "upload_tables") else [mem.upload(x) for x in host_tabs]
         # exactly one ambience and a fresh scene buffer (the normal case): added inside the mixdown kernel
         fused = list(ambience) if (len(ambience) == 1 and scene is None) else []
         ambience = [] if fused else list(ambience)

@@ -224,6 +224,7 @@ def _publish(event, mic_alias: str, res: engine.RenderResult, index: int) -> Non
     n_ch, n_samp = res.plan.n_capsules, int(res.plan.events["len"][index])
 
     def fetch():
+        res.check_finite()      # librosa.util.valid_audio of synthesize.py:603: raised when the render first meets the host
         out = res.spatial_audio(index)
         validate_shape(out.shape, (n_ch, n_samp))
         return out
@@ -263,11 +264,55 @@ def compute_dry_audio(event, irs: np.ndarray, event_scale: float, mic_alias: str
     event._spatial_audio_dry[mic_alias] = dry * event_scale
 
 
-def _dry_from_result(event, irs: np.ndarray, res: engine.RenderResult, index: int, emitter0: int, mic_alias: str):
-    if getattr(event, "ref_ir_channel", None) is None and getattr(event, "direct_path_time_ms", None) is None:
+def _wants_dry(event) -> bool:
+    return getattr(event, "ref_ir_channel", None) is not None and getattr(event, "direct_path_time_ms", None) is not None
+
+
+def _dry_batch(r: engine.Renderer, items, mic_alias: str, res: engine.RenderResult) -> None:
+    """The direct-path renders of ALL events of one microphone that ask for one (synthesize.py:432-504), as ONE batch of
+    one-capsule static events behind the main render instead of an upload / render / download round trip per event:
+    clip zero-padded to La + Lir - 1 (the dry render keeps the whole convolution), IR = the windowed row of the reference
+    capsule, UN-normalised; the emitter's normalisation gain and the event's noise-floor multiplier -- both results of the
+    main render -- are applied when ``event._spatial_audio_dry[mic]`` is first read, so nothing here waits for the GPU.
+    ``items``: [(event, mic_ir slice (C, N, L), index in ``res``, first IR column)]."""
+    todo = []
+    for event, irs, index, em0 in items:
+        ref, window = getattr(event, "ref_ir_channel", None), getattr(event, "direct_path_time_ms", None)
+        if ref is None and window is None:
+            continue
+        if ref is None or window is None:
+            logger.warning("Only one of `ref_ir_channel` or `direct_path_time` were specified when creating the Event. "
+                           "Dry audio will not be computed for this Event. Pass both variables to compute dry audio.")
+            continue
+        if ref > irs.shape[0]:
+            raise ValueError(f"Reference channel index out of range for IRs with {irs.shape[0]} channels")
+        if irs.shape[1] == 0:
+            continue
+        lo, hi = int(window[0] * event.sample_rate / 1000), int(window[1] * event.sample_rate / 1000)
+        ir = np.array(irs[ref, 0, :], dtype=np.float32)
+        peak = int(np.argmax(ir))     # the normalisation gain is positive: the peak of the normalised row is this one
+        if peak + hi < ir.shape[0]:
+            ir[peak + hi:] = 0
+        if peak - lo > 0:
+            ir[: peak - lo] = 0
+        clip = np.asarray(event.load_audio(ignore_cache=False), dtype=np.float32)
+        todo.append((event, ir, clip, index, em0))
+    if not todo:
         return
-    gain = float(res.memory.download(res.emitter_gain)[emitter0]) if irs.shape[1] else 1.0
-    compute_dry_audio(event, np.asarray(irs[:, :1, :], dtype=np.float64) * gain, float(res.stats()[index, 3]), mic_alias)
+    n_ir = todo[0][1].shape[0]
+    specs = [planning.EventSpec(n_samples=len(clip) + n_ir - 1, n_emitters=1, snr=1.0, emitter0=j)
+             for j, (_, _, clip, _, _) in enumerate(todo)]
+    clips = [np.concatenate([clip, np.zeros(n_ir - 1, np.float32)]) for _, _, clip, _, _ in todo]
+    pl = planning.plan_batch(specs, 1, n_ir, todo[0][0].sample_rate)
+    dry = r.prepare(pl, clips, np.stack([ir for _, ir, _, _, _ in todo])[None, :, :], normalize_irs=False)
+    dry_res = dry.run(("al_forward_spectra", "al_emitter_gains", "al_spectral_mac", "al_block_synthesis"))
+    for j, (event, _, _, index, em0) in enumerate(todo):
+        def fetch(j=j, index=index, em0=em0):
+            gain = float(res.memory.download(res.emitter_gain)[em0])
+            return dry_res.raw_spatial(j)[0].astype(np.float64) * (gain * float(res.stats()[index, 3]))
+
+        event._spatial_audio_dry = as_lazy(getattr(event, "_spatial_audio_dry", None))
+        LazyAudioDict.__setitem__(event._spatial_audio_dry, mic_alias, fetch)
 
 
 def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEFAULT_REF_DB,
@@ -286,10 +331,11 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
     spec = _spec_of(event, clip, n_emitters, 0, ref_db)
     pl = planning.plan_batch([spec], n_ch, max(n_ir, 1), event.sample_rate, hop=int(hop_size), win=int(win_size),
                              fft_size=int(fft_size))
-    res = get_renderer().render(pl, [clip], irs)
+    r = get_renderer()
+    res = r.render(pl, [clip], irs)
     res.check_finite()
     _publish(event, mic_alias, res, 0)
-    _dry_from_result(event, irs, res, 0, 0, mic_alias)
+    _dry_batch(r, [(event, irs, 0, 0)], mic_alias, res)
 
 
 def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = False) -> None:
@@ -331,26 +377,29 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
         if not specs:
             continue
         pl = planning.plan_batch(specs, mic_ir.shape[0], mic_ir.shape[2], scene.sample_rate)
+        # Only ENQUEUED here: nothing below waits for the GPU.  The finite check of the reference (librosa.util.valid_audio,
+        # synthesize.py:603) is made where the results first meet the host: in generate_scene_audio_from_events (one combined
+        # download of every statistic of the scene) or on the first read of event.spatial_audio[mic].
         res = r.render(pl, clips, mic_ir)
-        res.check_finite()
         for i, (event, em0) in enumerate(todo):
             _publish(event, mic_alias, res, i)
-            _dry_from_result(event, mic_ir[:, em0: em0 + len(event), :], res, i, em0, mic_alias)
+        _dry_batch(r, [(event, mic_ir[:, em0: em0 + len(event), :], i, em0) for i, (event, em0) in enumerate(todo)],
+                   mic_alias, res)
     logger.info(f"Rendered scene audio in {(time() - start):.2f} seconds!")
 
 
 # ----------------------------------------------------------------------------- mixdown
 def _device_source(r: engine.Renderer, event, mic_alias: str):
-    """(device buffer, offset, len, rows, scale buffer, scale index) of an event's render; uploads host
-    arrays that did not come from this package (scale 1)."""
+    """(device buffer, offset, len, rows, scale buffer, scale index, RenderResult or None) of an event's render; uploads
+    host arrays that did not come from this package (scale 1)."""
     sa = event.spatial_audio
     held = sa.device_source(mic_alias) if isinstance(sa, LazyAudioDict) else None
     if held is not None:
         res, idx = held
         ev = res.plan.events[idx]
-        return res.spatial, int(ev["out_off"]), int(ev["len"]), res.plan.n_capsules, res.event_scale, idx
+        return res.spatial, int(ev["out_off"]), int(ev["len"]), res.plan.n_capsules, res.event_scale, idx, res
     arr = np.ascontiguousarray(event.spatial_audio[mic_alias], dtype=np.float32)
-    return r.mem.upload(arr.reshape(-1)), 0, arr.shape[1], arr.shape[0], r.mem.upload(np.ones(1, np.float32)), 0
+    return r.mem.upload(arr.reshape(-1)), 0, arr.shape[1], arr.shape[0], r.mem.upload(np.ones(1, np.float32)), 0, None
 
 
 def generate_scene_audio_from_events(scene) -> None:
@@ -393,12 +442,30 @@ def generate_scene_audio_from_events(scene) -> None:
             scene_dev = pm.run()
             first = False
             _attach_padded(events, idxs, mix, mic_alias, channels, duration)
-        # librosa.util.valid_audio (synthesize.py:398) as a device reduction: a host pass over the scene costs more
-        # than rendering it
-        stats = r.mem.download(r.row_stats(scene_dev, 1, channels * duration)).reshape(-1, 4)
+        # librosa.util.valid_audio (synthesize.py:398,603) from device reductions (a host pass over the scene costs more than
+        # rendering it): the scene's statistics, every pending render's per-event statistics and the scene itself are
+        # downloaded behind ONE synchronisation, the scene's DMA enqueued first so that nothing waits in front of it.
+        pending = {}
+        for s_ in srcs:
+            held_res = s_[6]
+            if held_res is not None and not getattr(held_res, "_finite_ok", False):
+                pending[id(held_res)] = held_res
+        scene_stats_dev = r.row_stats(scene_dev, 1, channels * duration)
+        if hasattr(r.mem, "download_async"):
+            host_t = r.mem.download_async(scene_dev)
+            stats_t = r.mem.download_async(scene_stats_dev)
+            ev_t = {k: r.mem.download_async(v.event_stats) for k, v in pending.items()}
+            r.mem.synchronize()
+            host, stats = host_t.numpy(), stats_t.numpy().reshape(-1, 4)
+            ev_stats = {k: t.numpy() for k, t in ev_t.items()}
+        else:
+            host, stats = r.mem.download(scene_dev), r.mem.download(scene_stats_dev).reshape(-1, 4)
+            ev_stats = {k: r.mem.download(v.event_stats) for k, v in pending.items()}
+        for k, res_ in pending.items():
+            res_.check_finite(ev_stats[k][: 4 * len(res_.plan.events)].reshape(-1, 4))
         if stats[0, 2] > 0 or not np.isfinite(stats[0, 0]):
             raise ValueError("Audio buffer is not finite everywhere")
-        host = r.mem.download(scene_dev)[: channels * duration].reshape(channels, duration)
+        host = host[: channels * duration].reshape(channels, duration)
         validate_shape(host.shape, (channels, duration))
         scene.audio[mic_alias] = host
         # the mixed scene stays in HBM too: Scene.generate encodes the WAV frames from it on the device (al_encode_frames)
@@ -474,13 +541,15 @@ def _attach_padded(events, idxs, mix, mic_alias, channels, duration) -> None:
             return full
 
         LazyAudioDict.__setitem__(ev._spatial_audio_padded, mic_alias, fetch)
-        dry = getattr(ev, "_spatial_audio_dry", None) or {}
-        if dry.get(mic_alias) is not None:
-            if getattr(ev, "_spatial_audio_dry_padded", None) is None:
-                ev._spatial_audio_dry_padded = {}
-            line = np.zeros(duration, dtype=np.float32)
-            line[a:b] += pad_or_truncate_audio(dry[mic_alias][None, :], b - a)[0]
-            ev._spatial_audio_dry_padded[mic_alias] = line
+        dry = getattr(ev, "_spatial_audio_dry", None)
+        if dry is not None and mic_alias in dry:     # kept lazy like the dry render itself: no download unless somebody reads it
+            def fetch_dry(ev=ev, a=a, b=b):
+                line = np.zeros(duration, dtype=np.float32)
+                line[a:b] += pad_or_truncate_audio(np.asarray(ev._spatial_audio_dry[mic_alias])[None, :], b - a)[0]
+                return line
+
+            ev._spatial_audio_dry_padded = as_lazy(getattr(ev, "_spatial_audio_dry_padded", None))
+            LazyAudioDict.__setitem__(ev._spatial_audio_dry_padded, mic_alias, fetch_dry)
 
 
 def _sr_of(ev):

@@ -7,7 +7,18 @@ One "step" = one full pass of the hot path over one synthetic scene of the chose
 cfg2: 60 s scene, 32 capsules, 64 static events, 2 s RIRs, 48 kHz): the equivalents of
 render_audio_for_all_scene_events + generate_scene_audio_from_events with clips, IRs and tables
 already resident in HBM.  For N > 1 every rank renders its own scene (weak scaling, no data-path
-collective; the optional end-of-job gather is timed separately); rank 0 prints ONE JSON line.
+collective; the end-of-job gather is timed separately and rank 0 re-renders two peers' scenes to
+check the gathered buffers bit for bit); rank 0 prints ONE JSON line.
+
+Timing: W warm-up steps, then `--repeats` (default 3) repeats of EXACTLY K steps, each repeat bracketed by
+barrier + synchronize on both sides, max over ranks per repeat; `ms_per_step` / `value` come from the MEDIAN
+repeat (all repeats are in the JSON), so the driver's short `--steps 20` run does not hang on one outlier.
+Nothing but the launches is inside those regions; the per-kernel HIP-event durations come from one more
+pass of K steps right behind them.
+
+Other modes: `--total-scenes S` (cfg4: S scenes split over the ranks, every one rendered and ALL of them
+gathered on rank 0: strong scaling), `--shard capsules` (cfg5: ONE scene, its capsules split over the
+ranks, two all-reduces of per-emitter / per-event scalars inside the step).
 """
 import argparse
 import json
@@ -68,8 +79,8 @@ def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
         list(pool.map(_cpu_worker, jobs))
         wall = time.perf_counter() - t0
     total = wall * full / work
-    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=workers, kind="port", cpu_model=cpu_model(),
-                extrapolated=True,
+    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=workers, host_cores=os.cpu_count(), kind="port",
+                cpu_model=cpu_model(), extrapolated=True,
                 sample=f"{workers} events of one {scene.name} scene rendered concurrently, one oracle process each "
                        f"({wall:.1f} s wall), scaled linearly to the scene's events x IRs; mixdown not included")
 
@@ -184,36 +195,117 @@ def spawn_ranks(n: int) -> int:
     for rank in range(n):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # the build / GPU boxes export this already (their host driver only supports dmabuf IPC; without it RCCL fails with
+        # `hipIpcGetMemHandle: invalid argument`): kept for environments assembled by hand
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     codes = [p.wait() for p in procs]
     return next((c for c in codes if c), 0)
 
 
+def make_timers(emulate, torch):
+    class HostEvent:   # emulation only
+        def record(self):
+            self.t = time.perf_counter()
+
+        def elapsed_time(self, other):
+            return (other.t - self.t) * 1e3
+
+    def new_event():
+        return HostEvent() if emulate else torch.cuda.Event(enable_timing=True)
+
+    def device_sync():
+        if not emulate:
+            torch.cuda.synchronize()
+
+    return new_event, device_sync
+
+
+def timed_repeats(step, steps, warmup, repeats, barrier, device_sync, reduce_max):
+    """W warm-up steps, then `repeats` x (barrier, K steps, synchronize, barrier); per repeat the MAX over ranks.
+    Returns (seconds per repeat after the MAX, this rank's own seconds per repeat)."""
+    for _ in range(warmup):
+        step()
+    out, own = [], []
+    for _ in range(max(repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        for _k in range(steps):
+            step()
+        device_sync()
+        elapsed = time.perf_counter() - t0
+        barrier()
+        own.append(elapsed)
+        out.append(reduce_max(elapsed))
+    return out, own
+
+
+def make_renderer(emulate):
+    from audiblelight_amd import engine
+
+    if emulate:
+        from audiblelight_amd import _hip
+        from tests import hostemu
+
+        return engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
+    return engine.Renderer()   # raises without the HIP extension or a GPU: no fallback
+
+
+def resident_scene(r, scene, args):
+    """Inputs, tables and workspaces of one scene in HBM; returns (batch, mix, mix_plan, plan)."""
+    from audiblelight_amd import plan as planning
+
+    pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
+    batch = r.prepare(pl, scene.sources(), scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
+    n_ev = len(scene.clips)
+    mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
+                                     pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)
+    ambience = []
+    if scene.ambience_beta is not None:  # cfg5: white ambience drawn and scaled on the device, once (inputs resident)
+        from audiblelight_amd import ambience as amb
+        from audiblelight_amd.synthesize import _ambience_on_device
+
+        a = amb.Ambience(channels=scene.n_capsules, duration=scene.duration, alias="bench", noise=scene.ambience_beta,
+                         ref_db=-65, sample_rate=scene.sr, rng="device")
+        ambience = [_ambience_on_device(r, a, (scene.n_capsules, mix_plan.n_samples))]
+    mix = r.prepare_mixdown(mix_plan, batch.result(), ambience)
+    return batch, mix, mix_plan, pl
+
+
+def scene_tensor(mix, scene, mix_plan, emulate, torch):
+    t = mix.scene[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1)
+    return torch.from_numpy(t) if emulate else t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300, help="timed steps (default 300: about one second at cfg2)")
+    ap.add_argument("--steps", type=int, default=100, help="timed steps per repeat")
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=3, help="repeats of the K timed steps; the median is reported")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4", "cfg5"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the workload (debug only; reported in config)")
     ap.add_argument("--log2-block", type=int, default=None)
     ap.add_argument("--chunk-events", type=int, default=0, help="events per chunk (0 = whole scene in one batch)")
     ap.add_argument("--lanes", type=int, default=1, help="workspaces / HIP streams the chunks alternate over")
+    ap.add_argument("--total-scenes", type=int, default=0, metavar="S",
+                    help="batch mode (BASELINE configs[3]: --config cfg4 --total-scenes 256): one step = ALL S scenes, split over the "
+                         "ranks; every scene is rendered and all of them are gathered on rank 0 after the timed region")
+    ap.add_argument("--shard", default="scenes", choices=["scenes", "capsules"],
+                    help="capsules: ONE scene per step, its capsule rows split over the ranks (SURVEY 8e row 2; cfg5 secondary)")
     ap.add_argument("--cpu-events", type=int, default=None,
                     help="events timed for the CPU baseline (0 = skip; default: the whole scene for cfg2 = 18 s on one core, "
                          "a bounded sample for the larger configurations)")
-    ap.add_argument("--cpu-workers", type=int, default=0, metavar="N",
-                    help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64)")
+    ap.add_argument("--cpu-workers", type=int, default=-1, metavar="N",
+                    help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64; 0 = skip)")
     ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
                     help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; "
-                         "default 8 on one GPU, 0 otherwise)")
+                         "default 16 on one GPU, 0 otherwise)")
     ap.add_argument("--dropin", type=int, default=None, metavar="N",
                     help="also time N calls of Scene.generate() (the drop-in API: host numpy clips + IRs in, scene.audio "
-                         "out, synchronous; default 5 on one GPU for static configs, 0 otherwise)")
+                         "out, synchronous; default 8 on one GPU for static configs, 0 otherwise)")
     ap.add_argument("--graph", action="store_true",
-                    help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches; the per-stage "
-                         "times then come from a separate eager pass")
+                    help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
                     help="time an RCCL gather of the rendered scenes to rank 0 after the timed region (default: on for N > 1)")
     ap.add_argument("--no-gather", dest="gather", action="store_false")
@@ -230,12 +322,22 @@ def main():
     if args.gather is None:
         args.gather = world > 1
     if args.cpu_events is None:
-        args.cpu_events = {"cfg2": 64, "cfg3": 1, "cfg4": 16, "cfg5": 4}.get(args.config, 64)
+        args.cpu_events = {"cfg2": 64, "cfg3": 1, "cfg4": 32, "cfg5": 4}.get(args.config, 64)
+    plain = args.total_scenes == 0 and args.shard == "scenes"
     if args.end_to_end is None:
-        args.end_to_end = 16 if world == 1 else 0
+        args.end_to_end = 16 if (world == 1 and plain) else 0
     if args.dropin is None:
-        args.dropin = 5 if world == 1 else 0
+        args.dropin = 8 if (world == 1 and plain) else 0
     emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements
+
+    # SURVEY 8d (ii), the all-cores CPU figure: its worker processes are started HERE, before this process initialises the
+    # GPU (a GPU-initialised process must not be the parent of an exec on this pool), on the very scene the GPU renders
+    all_cores = None
+    if rank == 0 and world == 1 and plain and args.cpu_workers != 0 and not emulate:
+        from audiblelight_amd import synthetic
+
+        workers = min(os.cpu_count() or 1, 64) if args.cpu_workers < 0 else args.cpu_workers
+        all_cores = cpu_baseline_all_cores(synthetic.make_scene(args.config, scene_index=rank, scale=args.scale), workers)
 
     import torch
 
@@ -243,6 +345,7 @@ def main():
         torch.cuda.set_device(local_rank)
     backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path without N GPUs
     use_dist = world > 1 or os.environ.get("AL_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL init with one rank
+    dist = None
     if use_dist:
         import torch.distributed as dist
 
@@ -252,49 +355,78 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
             dist.init_process_group(backend)
+    new_event, device_sync = make_timers(emulate, torch)
+    coll_dev = "cuda" if (backend == "nccl" and not emulate) else "cpu"
 
-    from audiblelight_amd import engine, plan as planning, synthetic
+    def barrier():
+        device_sync()
+        if use_dist:
+            dist.barrier()
+        device_sync()
+
+    def reduce_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], device=coll_dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ranks(x):
+        """[x of rank 0, ..., x of rank N-1] on every rank: proof that the collective saw N ranks."""
+        if not use_dist:
+            return [x]
+        t = [torch.zeros(1, device=coll_dev, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(t, torch.tensor([x], device=coll_dev, dtype=torch.float64))
+        return [float(v.item()) for v in t]
+
+    ctx = dict(args=args, rank=rank, world=world, emulate=emulate, torch=torch, dist=dist, use_dist=use_dist, backend=backend,
+               all_cores=all_cores,
+               new_event=new_event, device_sync=device_sync, barrier=barrier, reduce_max=reduce_max, all_ranks=all_ranks)
+    if args.shard == "capsules":
+        out = run_capsule_sharded_mode(ctx)
+    elif args.total_scenes > 0:
+        out = run_scene_batch_mode(ctx)
+    else:
+        out = run_scene_per_rank_mode(ctx)
+    failed = bool(out.pop("_failed", False))
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.destroy_process_group()
+    if failed:
+        sys.exit(1)
+
+
+def base_record(ctx, scene, pl, value, rep_s, steps, scaling, extra_config):
+    args, world, emulate = ctx["args"], ctx["world"], ctx["emulate"]
+    med = float(np.median(rep_s))
+    return {
+        "metric": METRIC, "value": value, "unit": "scene-seconds/s",
+        "n_gpus": world, "steps": steps, "warmup": args.warmup,
+        "ms_per_step": med / steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic" if not emulate else "synthetic (HOST EMULATION of the kernels: not a measurement)",
+        "timing": {"repeats": len(rep_s), "ms_per_step_each_repeat": [round(x / steps * 1e3, 4) for x in rep_s],
+                   "reported": "median repeat; every repeat = exactly `steps` steps between barrier + synchronize, max over ranks",
+                   "ms_per_step_by_rank_last_repeat": None},
+        "config": dict({"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
+                        "chunk_events": args.chunk_events, "lanes": args.lanes, "hip_graph": bool(args.graph),
+                        "source_hash": source_hash()}, **extra_config),
+    }
+
+
+def run_scene_per_rank_mode(ctx):
+    """The headline: one scene per rank per step (weak scaling)."""
+    args, rank, world, emulate, torch = ctx["args"], ctx["rank"], ctx["world"], ctx["emulate"], ctx["torch"]
+    from audiblelight_amd import engine, synthetic
 
     scene = synthetic.make_scene(args.config, scene_index=rank, scale=args.scale)
-    if emulate:
-        from audiblelight_amd import _hip
-        from tests import hostemu
-
-        r = engine.Renderer(lib=_hip.Library(hostemu.build()), memory=hostemu.NumpyMemory())
-    else:
-        r = engine.Renderer()   # raises without the HIP extension or a GPU: no fallback
-    pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
-    batch = r.prepare(pl, scene.sources(), scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
+    r = make_renderer(emulate)
+    batch, mix, mix_plan, pl = resident_scene(r, scene, args)
     n_ev = len(scene.clips)
-    mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
-                                     pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)
-    ambience = []
-    if scene.ambience_beta is not None:  # cfg5: white ambience generated on the device, once (inputs resident)
-        from audiblelight_amd import ambience as amb
-        from audiblelight_amd.synthesize import _ambience_on_device
-
-        a = amb.Ambience(channels=scene.n_capsules, duration=scene.duration, alias="bench", noise=scene.ambience_beta,
-                         ref_db=-65, sample_rate=scene.sr)
-        ambience = [_ambience_on_device(r, a, (scene.n_capsules, mix_plan.n_samples))]
-    mix = r.prepare_mixdown(mix_plan, batch.result(), ambience)
     stages = list(batch.stage_names()) + ["al_mixdown"]
     chunked = len(batch.descs) > 1
-
     captured = engine.CapturedScene(batch, mix) if args.graph else None
-
-    class HostEvent:   # emulation only
-        def record(self):
-            self.t = time.perf_counter()
-
-        def elapsed_time(self, other):
-            return (other.t - self.t) * 1e3
-
-    def new_event():
-        return HostEvent() if emulate else torch.cuda.Event(enable_timing=True)
-
-    def device_sync():
-        if not emulate:
-            torch.cuda.synchronize()
 
     def step(events=None):
         if captured is not None and events is None:
@@ -314,108 +446,277 @@ def main():
             if events is not None:
                 events[i][1].record()
 
-    def barrier():
-        device_sync()
-        if use_dist:
-            dist.barrier()
-        device_sync()
-
-    for _ in range(args.warmup):
-        step()
-    # HIP events on the launch stream (torch's current stream is the stream every al_* call is given)
-    ev = [[(new_event(), new_event()) for _ in stages] for _ in range(args.steps)]
-    barrier()
+    rep_s, own_s = timed_repeats(step, args.steps, args.warmup, args.repeats, ctx["barrier"], ctx["device_sync"], ctx["reduce_max"])
+    # one more pass of K steps with HIP events on the launch stream (torch's current stream is the stream every al_* call
+    # is given) around every stage: the per-kernel durations, outside the regions `value` is computed from
+    ev = [[(ctx["new_event"](), ctx["new_event"]()) for _ in stages] for _ in range(args.steps)]
+    ctx["barrier"]()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(None if (chunked or captured is not None) else ev[k])
-    device_sync()
-    elapsed = time.perf_counter() - t0
-    barrier()
-    if captured is not None:  # per-stage durations from an eager pass outside the timed region
-        for k in range(args.steps):
-            step(ev[k])
-        device_sync()
-    if use_dist:
-        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        step(None if chunked else ev[k])
+    ctx["device_sync"]()
+    instrumented = time.perf_counter() - t0
+    by_rank = ctx["all_ranks"](own_s[-1] / args.steps * 1e3)
     batch.result().check_finite()
-
+    elapsed = float(np.median(rep_s))
+    ms_per_step = elapsed / args.steps * 1e3
     if chunked:
-        kernel_ms = {"al_render_batch+al_mixdown": elapsed / args.steps * 1e3}
+        kernel_ms = {"al_render_batch+al_mixdown": ms_per_step}
     else:
         kernel_ms = {name: float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(args.steps)]))
                      for i, name in enumerate(stages)}
     dominant = max(kernel_ms, key=kernel_ms.get)
     algo_bytes = scene.algorithmic_bytes()
     achieved = algo_bytes / (kernel_ms[dominant] * 1e-3) / 1e9
-    ms_per_step = elapsed / args.steps * 1e3
     pmc, pmc_note = (load_pmc_traffic(scene.name, pl.log2_block) if args.scale == 1.0 else (None, "reduced scale"))
-    out = {
-        "metric": METRIC,
-        "value": world * args.steps * scene.duration / elapsed,
-        "unit": "scene-seconds/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic" if not emulate else "synthetic (HOST EMULATION of the kernels: not a measurement)",
-        "config": {"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
-                   "scenes_per_step_per_gpu": 1, "chunk_events": args.chunk_events, "lanes": args.lanes,
-                   "hip_graph": bool(args.graph), "source_hash": source_hash()},
-        "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS,
-                     # the same algorithmic bytes over the WHOLE step (all kernels of the scene), per GPU
-                     "path_frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                     "traffic": (pmc or {}).get(dominant),
-                     # HBM rate on the bytes actually moved (PMC traffic / live duration): what the kernel is up against
-                     "traffic_rate": ((pmc or {}).get(dominant) or 0) / (kernel_ms[dominant] * 1e-3) / 1e9 or None,
-                     "traffic_note": pmc_note,
-                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
-                     "hbm_bytes_per_launch_pmc": pmc},
-    }
+    out = base_record(ctx, scene, pl, world * args.steps * scene.duration / elapsed, rep_s, args.steps, "weak",
+                      {"scenes_per_step_per_gpu": 1})
+    out["timing"]["ms_per_step_by_rank_last_repeat"] = [round(x, 4) for x in by_rank]
+    out["timing"]["ms_per_step_with_stage_events"] = instrumented / args.steps * 1e3
+    out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "frac": achieved / HBM_PEAK_GBS,
+                       # the same algorithmic bytes over the WHOLE step (all kernels of the scene), per GPU
+                       "path_frac": algo_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                       "traffic": (pmc or {}).get(dominant),
+                       # HBM rate on the bytes actually moved (PMC traffic / live duration): what the kernel is up against
+                       "traffic_rate": ((pmc or {}).get(dominant) or 0) / (kernel_ms[dominant] * 1e-3) / 1e9 or None,
+                       "traffic_note": pmc_note,
+                       "scene_traffic": sum(v for v in (pmc or {}).values() if isinstance(v, (int, float))) or None,
+                       "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
+                       "hbm_bytes_per_launch_pmc": pmc}
     if args.end_to_end > 0:
-        from audiblelight_amd import batch as batch_mod
-
-        jobs = [batch_mod.SceneJob(specs=scene.specs, clips=scene.clips, irs=scene.irs, starts=scene.starts, ends=scene.ends,
-                                   duration=scene.duration, sample_rate=scene.sr, name=f"s{i}") for i in range(args.end_to_end)]
-        driver = batch_mod.BatchDriver(r)
-        consume = lambda name, arr: None   # noqa: E731  (scene.audio delivered as a (C, T) float32 host array)
-        driver.run((jobs * 2)[:6], on_scene=consume, copy_for_callback=False)   # warm-up: page-locks every staging slot once
-        reps = [driver.run(jobs, on_scene=consume, copy_for_callback=False) for _ in range(3)]
-        rep = max(reps, key=lambda r_: r_.scene_seconds_per_second)   # best of three passes (host-side noise is large)
-        out["end_to_end"] = {"value": rep.scene_seconds_per_second, "unit": "scene-seconds/s", "scenes": rep.n_scenes,
-                             "passes": [round(r_.scene_seconds_per_second, 1) for r_ in reps],
-                             "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
-                             "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
-                             "note": "host float32 clips+IRs -> H2D -> render -> D2H of scene.audio into page-locked host memory, "
-                                     "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+        out["end_to_end"] = end_to_end_leg(r, scene, args.end_to_end)
     if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
         out["end_to_end_dropin"] = dropin_leg(scene, r, args.dropin)
-    if (args.gather and world > 1) or (use_dist and world == 1):
-        from audiblelight_amd import distributed
-
-        scene_t = mix.scene[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1)
-        if emulate:
-            scene_t = torch.from_numpy(scene_t)
-        barrier()
-        g0 = time.perf_counter()
-        got = distributed.gather_buffers({rank: scene_t}, world, dst=0, to_host=False)
-        device_sync()
-        g_ms = (time.perf_counter() - g0) * 1e3
-        if rank == 0:
-            assert sorted(got) == list(range(world)) and all(tuple(v.shape) == tuple(scene_t.shape) for v in got.values())
-        out["gather"] = {"ms": g_ms, "bytes_per_rank": int(scene_t.numel() * 4), "backend": backend,
-                         "note": "one (C, T) float32 scene per rank collected on rank 0's device after the timed region "
-                                 "(each peer sends over its own xGMI link); not part of `value`"}
-    if rank == 0:
-        if world == 1 and args.cpu_events > 0:
+    if (args.gather and world > 1) or (ctx["use_dist"] and world == 1):
+        out["gather"], ok = gather_and_validate(ctx, r, scene_tensor(mix, scene, mix_plan, emulate, torch),
+                                                lambda peer: rerender(ctx, r, peer))
+        out["_failed"] = not ok
+    if rank == 0 and world == 1:
+        if args.cpu_events > 0:
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))
-            if args.cpu_workers != 0:
-                workers = min(os.cpu_count() or 1, 64) if args.cpu_workers < 0 else args.cpu_workers
-                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(scene, workers)
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.destroy_process_group()
+        if ctx["all_cores"] is not None:
+            out["cpu_baseline_all_cores"] = ctx["all_cores"]
+    return out
+
+
+def rerender(ctx, r, peer):
+    """The scene rank `peer` renders, rendered here (same seed = same inputs; the path is deterministic)."""
+    from audiblelight_amd import synthetic
+
+    args = ctx["args"]
+    sc = synthetic.make_scene(args.config, scene_index=peer, scale=args.scale)
+    batch, mix, mix_plan, _ = resident_scene(r, sc, args)
+    batch.run()
+    mix.run()
+    ctx["device_sync"]()
+    return scene_tensor(mix, sc, mix_plan, ctx["emulate"], ctx["torch"])
+
+
+def gather_and_validate(ctx, r, mine, rerender_fn, n_items=None, local=None):
+    """End-of-job collection on rank 0 (point-to-point at exact sizes: every peer sends over its own xGMI link), timed
+    after the timed region, and SELF-VALIDATED: rank 0 renders the scenes of up to two peers itself and compares them with
+    what arrived, bit for bit.  Returns (json record, ok)."""
+    from audiblelight_amd import distributed
+
+    rank, world, torch = ctx["rank"], ctx["world"], ctx["torch"]
+    local = {rank: mine} if local is None else local
+    n_items = world if n_items is None else n_items
+    ctx["barrier"]()
+    g0 = time.perf_counter()
+    got = distributed.gather_buffers(local, n_items, dst=0, to_host=False)
+    ctx["device_sync"]()
+    g_ms = ctx["reduce_max"]((time.perf_counter() - g0) * 1e3)
+    seen = ctx["all_ranks"](float(rank))
+    rec = {"ms": g_ms, "bytes_total": None, "backend": ctx["backend"], "ranks_seen": sorted(int(x) for x in seen),
+           "note": "rendered (C, T) float32 scenes collected on rank 0's device after the timed region (each peer sends over "
+                   "its own xGMI link); not part of `value`"}
+    ok = True
+    if rank == 0:
+        ok = sorted(got) == list(range(n_items))
+        rec["bytes_total"] = int(sum(v.numel() * 4 for v in got.values()))
+        checked = {}
+        for item in sorted({i for i in (1, n_items - 1) if 0 < i < n_items and i % world != 0}):
+            want = rerender_fn(item)
+            same = tuple(got[item].shape) == tuple(want.shape) and bool(torch.equal(got[item].to(want.device), want))
+            checked[str(item)] = same
+            ok = ok and same
+        rec["validated_against_local_rerender"] = checked
+        rec["bit_exact"] = all(checked.values()) if checked else None
+    return rec, ok
+
+
+def end_to_end_leg(r, scene, n):
+    from audiblelight_amd import batch as batch_mod
+
+    jobs = [batch_mod.SceneJob(specs=scene.specs, clips=scene.clips, irs=scene.irs, starts=scene.starts, ends=scene.ends,
+                               duration=scene.duration, sample_rate=scene.sr, name=f"s{i}") for i in range(n)]
+    per_scene_ambience = scene.ambience_beta is not None
+    if per_scene_ambience:    # cfg5: every scene draws ITS OWN ambience on the device inside the pipeline (nothing is cached)
+        from audiblelight_amd import ambience as amb
+        from audiblelight_amd.synthesize import _ambience_on_device
+
+        class FreshAmbience:
+            def __init__(self, seed):
+                self.seed = seed
+
+            def __iter__(self):
+                a = amb.Ambience(channels=scene.n_capsules, duration=scene.duration, alias="a", noise=scene.ambience_beta,
+                                 ref_db=-65, sample_rate=scene.sr, rng="device", seed=self.seed)
+                return iter([_ambience_on_device(r, a, (scene.n_capsules, round(scene.duration * scene.sr)))])
+
+            def __len__(self):
+                return 1
+
+        for i, job in enumerate(jobs):
+            job.clips = scene.sources()
+            job.ambience = FreshAmbience(1000 + i)
+    driver = batch_mod.BatchDriver(r)
+    consume = lambda name, arr: None   # noqa: E731  (scene.audio delivered as a (C, T) float32 host array)
+    driver.run((jobs * 2)[:6], on_scene=consume, copy_for_callback=False)   # warm-up: page-locks every staging slot once
+    reps = [driver.run(jobs, on_scene=consume, copy_for_callback=False) for _ in range(3)]
+    rep = max(reps, key=lambda r_: r_.scene_seconds_per_second)   # best of three passes (host-side noise is large)
+    return {"value": rep.scene_seconds_per_second, "unit": "scene-seconds/s", "scenes": rep.n_scenes,
+            "passes": [round(r_.scene_seconds_per_second, 1) for r_ in reps],
+            "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
+            "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
+            "ir_upload_bound": "one scene's IR tensor over PCIe at 56 GB/s = %.1f ms" % (scene.irs.nbytes / 56e9 * 1e3),
+            "ms_per_scene": 1e3 * rep.wall_s / max(rep.n_scenes, 1),
+            "ambience": "drawn per scene on the device (Philox), never on the host" if per_scene_ambience else None,
+            "note": "host float32 clips+IRs -> H2D -> render -> D2H of scene.audio into page-locked host memory, "
+                    "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+
+
+def run_scene_batch_mode(ctx):
+    """BASELINE configs[3]: a batch of S independent scenes split over the ranks (rank r owns scenes r, r + N, ...), every
+    scene rendered in full, ALL of them gathered on rank 0 after the timed region.  One step = the whole batch: strong
+    scaling.  The inputs of `--input-sets` distinct scenes per rank stay resident and are reused cyclically (generating
+    256 x 220 MB of random inputs on the host would take minutes and measure nothing); every scene has its own output."""
+    args, rank, world, emulate, torch = ctx["args"], ctx["rank"], ctx["world"], ctx["emulate"], ctx["torch"]
+    from audiblelight_amd import distributed, synthetic
+
+    r = make_renderer(emulate)
+    mine = distributed.shard_indices(args.total_scenes, rank, world)
+    n_sets = max(1, min(4, len(mine)))
+    sets = []
+    for j in range(n_sets):
+        sc = synthetic.make_scene(args.config, scene_index=(mine[j] if j < len(mine) else rank), scale=args.scale)
+        sets.append((sc,) + resident_scene(r, sc, args))
+    scene0, pl0 = sets[0][0], sets[0][4]
+    n_out = scene0.n_capsules * sets[0][3].n_samples
+    outputs = [r.mem.empty(n_out) for _ in mine]     # one (C, T) buffer per scene of this rank: what the gather collects
+
+    def step():
+        for j, out_buf in enumerate(outputs):
+            sc, batch, mix, mix_plan, _pl = sets[j % n_sets]
+            batch.run()
+            mix.run()
+            if emulate:
+                out_buf[:n_out] = mix.scene[:n_out]
+            else:
+                out_buf[:n_out].copy_(mix.scene[:n_out], non_blocking=True)   # D2D: the next scene of this input set reuses mix.scene
+
+    rep_s, own_s = timed_repeats(step, args.steps, args.warmup, args.repeats, ctx["barrier"], ctx["device_sync"], ctx["reduce_max"])
+    by_rank = ctx["all_ranks"](own_s[-1] / args.steps * 1e3)
+    elapsed = float(np.median(rep_s))
+    out = base_record(ctx, scene0, pl0, args.steps * args.total_scenes * scene0.duration / elapsed, rep_s, args.steps, "strong",
+                      {"total_scenes": args.total_scenes, "scenes_this_rank": len(mine), "distinct_input_sets_per_rank": n_sets,
+                       "note": "one step = the whole batch; outputs copied device-to-device into per-scene buffers inside the step"})
+    out["timing"]["ms_per_step_by_rank_last_repeat"] = [round(x, 4) for x in by_rank]
+    algo = scene0.algorithmic_bytes() * args.total_scenes
+    out["roofline"] = {"bound": "hbm", "kernel": "whole step (all scenes of the batch)", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "achieved": algo / elapsed * args.steps / 1e9 / world, "frac": algo / elapsed * args.steps / 1e9 / world / HBM_PEAK_GBS,
+                       "traffic": None, "algorithmic_bytes_per_step": algo}
+    if ctx["use_dist"]:
+        as_t = (lambda b: torch.from_numpy(b[:n_out]).reshape(scene0.n_capsules, -1)) if emulate else \
+            (lambda b: b[:n_out].reshape(scene0.n_capsules, -1))
+        local = {idx: as_t(buf) for idx, buf in zip(mine, outputs)}
+
+        def rerender_item(item):
+            j = (item // world) % n_sets     # which input set the owner used for that scene
+            owner = item % world
+            sc = synthetic.make_scene(args.config, scene_index=distributed.shard_indices(args.total_scenes, owner, world)[j],
+                                      scale=args.scale)
+            batch, mix, mix_plan, _ = resident_scene(r, sc, args)
+            batch.run()
+            mix.run()
+            ctx["device_sync"]()
+            return scene_tensor(mix, sc, mix_plan, emulate, torch)
+
+        out["gather"], ok = gather_and_validate(ctx, r, None, rerender_item, n_items=args.total_scenes, local=local)
+        out["_failed"] = not ok
+    return out
+
+
+def run_capsule_sharded_mode(ctx):
+    """SURVEY 8e row 2 / cfg5 secondary: ONE scene per step, rank r owns capsule rows capsule_slice(C, r, N) of every event;
+    the only exchanges are two all-reduces of per-emitter / per-event scalars on device arrays (timed separately); every
+    rank mixes its own rows.  After the timed region the rows are gathered on rank 0 and compared with rank 0's own render
+    of the WHOLE scene (float32 rounding of the level law's partial sums: tolerance, not bit-exactness)."""
+    args, rank, world, emulate, torch = ctx["args"], ctx["rank"], ctx["world"], ctx["emulate"], ctx["torch"]
+    from audiblelight_amd import distributed, plan as planning, synthetic
+
+    scene = synthetic.make_scene(args.config, scene_index=0, scale=args.scale)    # the SAME scene on every rank
+    r = make_renderer(emulate)
+    C = scene.n_capsules
+    sl = distributed.capsule_slice(C, rank, world)
+    rows = sl.stop - sl.start
+    batch = distributed.prepare_capsule_sharded(r, scene.specs, scene.sources(), np.ascontiguousarray(scene.irs[sl]), C, scene.sr,
+                                                log2_block=args.log2_block)
+    pl = batch.plan
+    n_ev = len(scene.clips)
+    mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [rows] * n_ev, pl.events["out_off"],
+                                     list(range(n_ev)), scene.duration, scene.sr, rows)
+    mix = r.prepare_mixdown(mix_plan, batch.result(), [])
+    timers = {"make_event": ctx["new_event"]}
+
+    def step(t=None):
+        distributed.run_capsule_sharded(r, batch, C, timers=t)
+        mix.run()
+
+    rep_s, own_s = timed_repeats(step, args.steps, args.warmup, args.repeats, ctx["barrier"], ctx["device_sync"], ctx["reduce_max"])
+    ctx["barrier"]()
+    for _ in range(args.steps):     # instrumented pass: the two exchanges between HIP events on the launch stream
+        step(timers)
+    ctx["device_sync"]()
+    coll = {k: float(np.mean([a.elapsed_time(b) for a, b in v])) for k, v in timers.items() if k != "make_event"}
+    by_rank = ctx["all_ranks"](own_s[-1] / args.steps * 1e3)
+    elapsed = float(np.median(rep_s))
+    out = base_record(ctx, scene, pl, args.steps * scene.duration / elapsed, rep_s, args.steps, "strong",
+                      {"shard": "capsules", "capsules_this_rank": rows, "scenes_per_step": 1})
+    out["timing"]["ms_per_step_by_rank_last_repeat"] = [round(x, 4) for x in by_rank]
+    out["collectives_ms"] = dict(coll, note="mean device time per step between HIP events around each exchange (includes "
+                                            "waiting for the slowest rank): per-emitter IR norm sums (SUM) before the accumulate, "
+                                            "E x {sum|x|, #non-finite} (SUM) + E x max|x| (MAX) before the level law")
+    algo = scene.algorithmic_bytes()
+    out["roofline"] = {"bound": "hbm", "kernel": "whole step", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                       "achieved": algo / world / (elapsed / args.steps) / 1e9,
+                       "frac": algo / world / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                       "algorithmic_bytes_per_launch": algo}
+    if ctx["use_dist"]:
+        mine = mix.scene[: rows * mix_plan.n_samples].reshape(rows, -1)
+        mine = torch.from_numpy(mine) if emulate else mine
+        ctx["barrier"]()
+        g0 = time.perf_counter()
+        got = distributed.gather_buffers({rank: mine}, world, dst=0, to_host=False)
+        ctx["device_sync"]()
+        g_ms = ctx["reduce_max"]((time.perf_counter() - g0) * 1e3)
+        rec = {"ms": g_ms, "backend": ctx["backend"], "ranks_seen": sorted(int(x) for x in ctx["all_ranks"](float(rank)))}
+        if rank == 0:
+            whole = torch.cat([got[i] for i in range(world)], dim=0)
+            single = synthetic.make_scene(args.config, scene_index=0, scale=args.scale)
+            b1, m1, mp1, _ = resident_scene(r, single, argparse.Namespace(**dict(vars(args), chunk_events=0, lanes=1)))
+            # resident_scene adds cfg5's ambience; the sharded step does not mix one: compare event mixes only
+            m1 = r.prepare_mixdown(mp1, b1.result(), [])
+            b1.run()
+            m1.run()
+            ctx["device_sync"]()
+            ref = scene_tensor(m1, single, mp1, emulate, torch).to(whole.device)
+            err = float(((whole - ref).double().pow(2).mean().sqrt() / ref.double().pow(2).mean().sqrt()).item())
+            rec.update(rows_total=int(whole.shape[0]), rel_rms_vs_single_gpu_render=err, within_tolerance=err < 1e-5)
+            out["_failed"] = not (whole.shape == ref.shape and err < 1e-5)
+        out["gather"] = rec
+    return out
 
 
 if __name__ == "__main__":

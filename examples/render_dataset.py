@@ -2,8 +2,9 @@
 """A dataset of synthetic scenes through the pipelined driver, on one GPU or one process per GPU.
 
     python examples/render_dataset.py out/ 16                                           # one GPU
+    python examples/render_dataset.py out/ 256 --gpus 8                                 # 8 GPUs: starts one process per GPU itself
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \\
-        examples/render_dataset.py out/ 256                                             # 8 GPUs, scenes round-robin
+        examples/render_dataset.py out/ 256                                             # the same under a launcher
 
 What the reference does in a serial loop (scripts/generate/benchmark.py:44-77, scripts/seld/generate_dataset.py:96-260):
 one folder per scene with a WAV per microphone ((T, C) PCM_16 frames) and ``metadata_out.json``; folders that exist are
@@ -38,7 +39,27 @@ def make_scene(index: int):
     return scene
 
 
-def main(out_dir="dataset_out", n_scenes="8"):
+def spawn_ranks(n: int, argv) -> int:
+    """One fresh child process per GPU, started BEFORE this process has touched the GPU (a process that has initialised the
+    GPU must never exec another program); the children share nothing but the output directory, so there is no rendezvous."""
+    import subprocess
+
+    procs = []
+    for rank in range(n):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+        env.setdefault("AL_AMBIENCE_RNG", "device")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    codes = [p.wait() for p in procs]
+    return next((c for c in codes if c), 0)
+
+
+def main(out_dir="dataset_out", n_scenes="8", *flags):
+    if "--gpus" in flags and "RANK" not in os.environ:
+        n = int(flags[flags.index("--gpus") + 1])
+        if n > 1:
+            sys.exit(spawn_ranks(n, [out_dir, n_scenes]))
+    # ambience noise drawn on the device (Philox) unless the caller asks for the reference's host PCG64 realisation
+    os.environ.setdefault("AL_AMBIENCE_RNG", "device")
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         import torch

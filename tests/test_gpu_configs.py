@@ -371,11 +371,12 @@ def test_bench_collectives_on_rccl_with_one_rank():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["AL_BENCH_FORCE_DIST"] = "1"
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "20", "--cpu-events", "0",
-                          "--end-to-end", "0", "--dropin", "0"], env=env, capture_output=True, text=True, timeout=600)
+                          "--cpu-workers", "0", "--end-to-end", "0", "--dropin", "0"], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
     out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
-    assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_per_rank"] == 4 * 4 * 240000
-    assert out["data"] == "synthetic" and out["value"] > 0
+    assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_total"] == 4 * 4 * 240000
+    assert out["data"] == "synthetic" and out["value"] > 0 and out["gather"]["ranks_seen"] == [0]
+    assert out["timing"]["repeats"] == 3 and out["steps"] == 20
 
 
 def test_float64_irs_host_cast_equals_device_cast(gpu, monkeypatch):

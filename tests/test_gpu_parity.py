@@ -184,7 +184,7 @@ def test_full_size_properties(gpu, planning, name):
         assert rel_rms(res.raw_spatial(e)[c], ref * gains[e]) < TOL
         e_ref = orc.emitter_gains(sc.irs[:, [e], :].astype(np.float64))[0]
         assert gains[e] == pytest.approx(e_ref, rel=1e-5)
-    # mixdown: linearity check on one capsule against a host-side sum of the device renders
+    # mixdown of the whole scene: every output sample is the float32 sum the kernel's own inputs imply (all 64 events)
     mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [sc.n_capsules] * len(sc.clips),
                                 pl.events["out_off"], list(range(len(sc.clips))), sc.duration, sc.sr, sc.n_capsules)
     scene = gpu.mem.download(gpu.mixdown(mix, res))[: sc.n_capsules * mix.n_samples].reshape(sc.n_capsules, -1)
@@ -194,6 +194,20 @@ def test_full_size_properties(gpu, planning, name):
         a0, b0 = planning.event_slot(sc.starts[e], sc.ends[e], sc.sr, mix.n_samples)
         want[a0:b0] += (res.raw_spatial(e)[c].astype(np.float64) * scales[e])[: b0 - a0]
     assert rel_rms(scene[c], want) < 1e-6
+    # ... and against the ORACLE's scene at full length (60 s, all 32 capsules, every row) for the first six events: the
+    # whole chain render -> level law -> mixdown, nothing taken from the device (the oracle needs 0.3 s per full-size event)
+    n6 = 6
+    pl6 = planning.plan_batch(sc.specs[:n6], sc.n_capsules, sc.ir_len, sc.sr)
+    res6 = gpu.render(pl6, sc.clips[:n6], sc.irs[:, :n6, :])
+    mix6 = planning.plan_mixdown(sc.starts[:n6], sc.ends[:n6], [len(c) for c in sc.clips[:n6]], [sc.n_capsules] * n6,
+                                 pl6.events["out_off"], list(range(n6)), sc.duration, sc.sr, sc.n_capsules)
+    scene6 = gpu.mem.download(gpu.mixdown(mix6, res6))[: sc.n_capsules * mix6.n_samples].reshape(sc.n_capsules, -1)
+    spat = [orc.render_event(sc.clips[e], sc.irs[:, [e], :].astype(np.float64), sc.specs[e].snr, sc.specs[e].ref_db, sr=sc.sr)["spatial"]
+            for e in range(n6)]
+    ref6 = orc.mix_scene(spat, list(zip(sc.starts[:n6], sc.ends[:n6])), sc.duration, sc.sr, keep_padded=False)["scene"]
+    assert scene6.shape == ref6.shape == (sc.n_capsules, 2880000)
+    for row in range(sc.n_capsules):
+        assert rel_rms(scene6[row], ref6[row]) < TOL, row
 
 
 @pytest.mark.parametrize("seed", range(12))

@@ -141,7 +141,8 @@ def test_bench_cpu_baseline_leg_runs_on_a_small_sample():
 
 def test_bench_gpus_flag_spawns_that_many_ranks():
     """`python bench.py --gpus 2` starts two rank processes itself (gloo + host-emulated kernels here; RCCL + gfx950 on
-    the GPU box) and rank 0 prints ONE JSON line with n_gpus == 2, a gather figure and the per-step roofline fields."""
+    the GPU box) and rank 0 prints ONE JSON line with n_gpus == 2, a SELF-VALIDATED gather and the per-step roofline
+    fields; the scene-batch mode (cfg4's contract) and the capsule-sharded mode (cfg5's secondary contract) likewise."""
     import json
     import subprocess
     import sys
@@ -154,14 +155,32 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     env.update(AL_BENCH_EMULATE="1", AL_DIST_BACKEND="gloo")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--config", "cfg1",
            "--scale", "0.05", "--cpu-events", "0"]
-    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    def run(extra):
+        res = subprocess.run(cmd + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    out = run([])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0
-    assert out["gather"]["bytes_per_rank"] > 0 and 0 < out["roofline"]["path_frac"] <= out["roofline"]["frac"]
+    assert 0 < out["roofline"]["path_frac"] <= out["roofline"]["frac"]
     assert "HOST EMULATION" in out["data"]
+    assert out["timing"]["repeats"] == 3 and len(out["timing"]["ms_per_step_each_repeat"]) == 3
+    assert len(out["timing"]["ms_per_step_by_rank_last_repeat"]) == 2
+    # the first multi-rank run validates itself: rank 0 renders rank 1's scene again and compares the gathered buffer bit for bit
+    g = out["gather"]
+    assert g["bytes_total"] > 0 and g["ranks_seen"] == [0, 1] and g["validated_against_local_rerender"] == {"1": True} and g["bit_exact"]
+    # BASELINE configs[3] as a mode: a batch of scenes split over the ranks, ALL of them gathered and two of them re-rendered
+    out = run(["--total-scenes", "4", "--repeats", "1"])
+    assert out["scaling"] == "strong" and out["config"]["total_scenes"] == 4 and out["config"]["scenes_this_rank"] == 2
+    assert out["gather"]["validated_against_local_rerender"] == {"1": True, "3": True} and out["gather"]["bit_exact"]
+    assert out["gather"]["bytes_total"] == 4 * (4 * 12000 * 4)      # ALL four (4 capsules x 12 000 samples) scenes arrived
+    # SURVEY 8e row 2 as a mode: ONE scene, capsule rows split over the ranks, two all-reduces inside the step
+    out = run(["--shard", "capsules", "--repeats", "1"])
+    assert out["config"]["shard"] == "capsules" and out["config"]["capsules_this_rank"] == 2 and out["scaling"] == "strong"
+    assert set(out["collectives_ms"]) >= {"allreduce_ir_norms", "allreduce_event_levels"}
+    assert out["gather"]["rows_total"] == 4 and out["gather"]["within_tolerance"]
     # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
     bad = subprocess.run(cmd, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr

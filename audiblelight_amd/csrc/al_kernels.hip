@@ -118,7 +118,7 @@ template <> struct BinVec<2> {
 
 // k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
 __host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
-  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 16 && b.log2_block >= 9;
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 18 && b.log2_block >= 9;
 }
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
@@ -1077,9 +1077,11 @@ MacPlan plan_mac(const al_batch *b) {
     // flags bit 12 (A/B switch): one k-tile per workgroup; bit 13 (A/B switch): register version beyond 24 blocks
     const bool pair = n_ktiles > 1 && !(b->flags & (1 << 12));
     const int n_pairs = (n_ktiles + 1) / 2;
-    if (P > 12) {   // 13..16 partitions: two units of ceil(P/2) per capsule, always through LDS, always two k-tiles per workgroup
+    if (P > 12) {   // 13..16 partitions: two units of ceil(P/2) per capsule, 17 / 18: three units of 6; always through LDS,
+      const int units = P > 16 ? 3 : 2;   // always two k-tiles per workgroup.  (Three units of 7 / 8 for 19..24 partitions spill 84 /
+                                          // 132 B per lane and lose to the tile kernels: profiles/r03_p24_ab.txt.)
       m.static_kind = MAC_STATIC_LDS_UNITS;
-      m.static_pt = (P + 1) / 2;
+      m.static_pt = (P + units - 1) / units;
       m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
       m.static_threads = 512;
     } else if (pair && n_pairs > 1 && !(b->flags & (1 << 13))) {
@@ -1193,8 +1195,12 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
   const MacPlan m = plan_mac(b);
   const int bins = 1 << b->log2_block;
   if (m.static_kind == MAC_STATIC_LDS_UNITS) {
-    if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
-    else hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    if (b->n_partitions <= 16) {
+      if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
+      else hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    } else {
+      hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 6, 3>), m.static_grid, dim3(512), 0, stream, *b);
+    }
     if (int rc = check_launch("k_spectral_mac_static_lds")) return rc;
   } else if (m.static_kind != MAC_STATIC_NONE) {
     switch (m.static_pt) {   // the partition tile IS the partition count: no masked partitions in the loop

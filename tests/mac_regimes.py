@@ -25,14 +25,14 @@ STATIC_CASES = [
     ("tile_8_4_1", 80401, 3.0, 2.0),                 # exact multiples: K = 3, P = 2
 ]
 
-# k_spectral_mac_static<12,P,{1,2}> / k_spectral_mac_static_lds<12,P> / <12,ceil(P/2),2>: EVERY partition count 1..16 in each of
-# the three clip-length regimes that pick a different instantiation (or, for 13..16 partitions, a different grid of the same one):
+# k_spectral_mac_static<12,P,{1,2}> / k_spectral_mac_static_lds<12,P> / <12,ceil(P/2),2> / <12,6,3>: EVERY partition count 1..18 in each of
+# the three clip-length regimes that pick a different instantiation (or, for 13..18 partitions, a different grid of the same one):
 # (name, expected code 3120000 + 100*P + {1: one k-tile per workgroup, 2: two, 3: partition spectra staged through LDS},
 #  K multiple, P multiple, capsules, events); one event => the capsule loop is split into ranges (small batch)
 _CLIP_REGIMES = (("one_ktile", 9.3, 1), ("two_ktiles", 20.6, 2), ("beyond_24_blocks", 26.3, 3))
 STATIC_LOOP_CASES = [
     (f"P{P}_{name}", 3120000 + 100 * P + (3 if P > 12 else digit), k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
-    for P in range(1, 17) for name, k_mult, digit in _CLIP_REGIMES]
+    for P in range(1, 19) for name, k_mult, digit in _CLIP_REGIMES]
 STATIC_LOOP_CASES += [   # hand-picked edges kept from round 2
     ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
     ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
@@ -64,7 +64,9 @@ def codes_of_kernel_symbol(sym: str):
         return [("static", 3120000 + 100 * pt + last)]
     if last == 1:
         return [("static", 3120000 + 100 * pt + 3)]
-    return [("static", 3120000 + 100 * p + 3) for p in (2 * pt - 1, 2 * pt)]   # two units per capsule: P = 2*PT - 1 and 2*PT
+    if last == 2:
+        return [("static", 3120000 + 100 * p + 3) for p in (2 * pt - 1, 2 * pt)]   # two units per capsule: P = 2*PT - 1 and 2*PT
+    return [("static", 3120000 + 100 * p + 3) for p in (17, 18)]                   # three units of 6: P = 17, 18
 
 
 def asserted_codes():

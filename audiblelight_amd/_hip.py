@@ -24,7 +24,7 @@ FLAG_STATIC_MAC = 64
 FLAG_ONLY_STATIC = 128
 FLAG_NARROW_FFT = 4
 # bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
-DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (3 << 12) | (0xff << 16) | (0x7f << 24)   # bit 12: static accumulate, one k-tile per workgroup
+DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (7 << 12) | (0xff << 16) | (0x7f << 24)   # bit 12: static accumulate, one k-tile per workgroup
 
 # numpy mirrors of al_event / al_stream (the tables are built on the host and copied to HBM)
 EVENT_DTYPE = np.dtype([

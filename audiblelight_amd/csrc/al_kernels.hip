@@ -118,7 +118,9 @@ template <> struct BinVec<2> {
 
 // k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
 __host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
-  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= 18 && b.log2_block >= 9;
+  // up to 24 partitions through the LDS-DMA kernel (it reads the rows past an odd partition count from the all-zero block),
+  // up to 16 through the register-staged one when the caller gave no zero block
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= (b.hspec_zero_block >= 0 ? 24 : 16) && b.log2_block >= 9;
 }
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
@@ -426,6 +428,179 @@ __global__ __launch_bounds__(512, 2) void k_spectral_mac_static_lds(al_batch b) 
   __shared__ float4 hbuf[3 * PT * 256];
   if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, UNITS, true>(b, hbuf);
   else spectral_mac_static_lds_body<KT, PT, UNITS, false>(b, hbuf);
+}
+
+// ------------------------------------------------------------------ 4a'. capsule loop fed by LDS-DMA
+// The same loop with the partition spectra brought into the LDS ring by LDS-DMA (global_load_lds_dwordx4: the data never
+// passes through a VGPR and the instruction returns at once).  A wave has only two register sets' worth of room, so the
+// register versions request capsule c+1's spectra WHILE capsule c is multiplied -- one iteration (a few microseconds) of
+// flight time, less than the latency of a loaded HBM (profiles/r02_mac.txt 9).  Here the request for unit n+2 is issued at the
+// start of unit n and retired by a COUNTED s_waitcnt at the start of unit n+2: two iterations in flight, no staging
+// registers, no ds_write pass.  Protocol per unit n (cdna_hip_programming.md section 5, "Pipelining across barriers"):
+//     s_waitcnt vmcnt(N)   this wave's DMA pieces of unit n have landed (N = the VMEM operations it issued after them:
+//                          the pieces of unit n+1 and the Y stores in between; VMEM operations of a wave retire in order)
+//     s_barrier            ... and so have every other wave's; everybody is done reading the stage unit n+2 will overwrite
+//     issue DMA of unit n+2 -> stage (n+2) % 3;   multiply unit n out of stage n % 3;   store Y at the end of a capsule
+// The DMA is inline asm (hipcc would drain every outstanding one with vmcnt(0) before the first LDS read it knows to depend
+// on it); the waits are therefore counted by hand.  Every wave issues the same number of pieces (the last piece is fetched
+// again where PT * 4 is not a multiple of 8) and every half issues exactly its own number of stores per capsule.
+#if defined(__HIP_DEVICE_COMPILE__)
+// 64 lanes x 16 B from (uniform base in SGPRs) + (lane offset in ONE VGPR shared by every piece) into LDS at lds_dst + lane * 16:
+// all the address arithmetic of a piece is scalar
+__device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#endif
+
+// NL: the NL signal blocks at EACH end of the window live in LDS instead of registers.  Block jj of the window meets
+// min(jj + 1, NJ - jj, KT) products per capsule, so the ends are the cheap ones to re-read: NL = 3 costs 12 extra
+// ds_read_b128 per capsule and frees 24 VGPRs, which is what the 35-block window of 22..24 partitions needs to stay
+// out of scratch memory (a spill reload would also drain the LDS-DMA in flight: hipcc waits vmcnt(0) for it).
+template <int KT, int PT, int UNITS, bool BIN0, bool ZERO_ROWS = (UNITS > 1), int NL = 0>
+__device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b, float4 *hbuf, float4 *xbuf = nullptr) {
+  using V = BinVec<2>;
+  constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PIECES = PT * 4, PER_WAVE = (PIECES + 7) / 8;
+  const int M = 1 << b.log2_block;
+  const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8, lane = threadIdx.x & 63;
+  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int n_cs = gridDim.z / b.n_events;
+  const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
+  const al_event ev = b.events[b.event0 + e];
+  if (ev.n_streams != 1) return;
+  const int K = ev.n_blocks, P = b.n_partitions, C = b.n_capsules;
+  const int k0 = (blockIdx.y * 2 + sub) * KT;
+  const bool active = k0 < K;
+  const int n_stores = active ? min(KT, K - k0) : 0;            // Y stores this half issues per capsule (workgroup-half uniform)
+  const int c_begin = (int)((int64_t)cs * C / n_cs), c_end = (int)((int64_t)(cs + 1) * C / n_cs);
+  const al_stream st = b.streams[ev.stream0];
+  const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
+  const bool packed = (f == 0);
+  const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
+  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + blockIdx.x * 512;
+  const float2 *__restrict__ Hzero = reinterpret_cast<const float2 *>(b.hspec) + (int64_t)max(b.hspec_zero_block, 0) * M;   // rows past P (odd P in units)
+  float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + k0) * M + f;
+  const float g = b.emitter_gain[st.emitter];
+  V xw[NJ - 2 * NL];                                            // window blocks [NL, NJ - NL); the ends are in xbuf
+  if (active) {
+    const int jbase = k0 - (PALL - 1);
+    static_for<NJ>([&](auto jj_c) {
+      constexpr int jj = decltype(jj_c)::value;
+      const int j = jbase + jj;
+      V x = V::load(X + (int64_t)min(max(j, jlo), jhi - 1) * M);
+      x.scale((j >= jlo && j < jhi) ? g : 0.f);
+      if constexpr (jj < NL) xbuf[jj * 512 + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
+      else if constexpr (jj >= NJ - NL) xbuf[(jj - (NJ - 2 * NL)) * 512 + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
+      else xw[jj - NL] = x;
+    });
+  }
+  auto window = [&](auto jj_c) -> V {                          // a thread reads back only what it wrote: no barrier needed
+    constexpr int jj = decltype(jj_c)::value;
+    if constexpr (jj < NL || jj >= NJ - NL) {
+      const float4 v = xbuf[(jj < NL ? jj : jj - (NJ - 2 * NL)) * 512 + threadIdx.x];
+      return V{make_float2(v.x, v.y), make_float2(v.z, v.w)};
+    } else {
+      return xw[jj - NL];
+    }
+  };
+  const int n_units = UNITS * (c_end - c_begin);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  __attribute__((address_space(3))) float4 *hbuf_lds = (__attribute__((address_space(3))) float4 *)hbuf;
+  const unsigned lds_base = (unsigned)(uintptr_t)hbuf_lds;      // byte offset of the ring inside the workgroup's LDS
+#else
+  const int wave = (int)(threadIdx.x >> 6);
+#endif
+  // unit n = (capsule c_begin + n / UNITS, partitions [(n % UNITS) * PT, +PT)); piece q of row r = 1 KB = 64 lanes x 16 B
+  auto issue = [&](int n) {
+    const int n_ = min(n, n_units - 1), cc = c_begin + n_ / UNITS, p0 = (n_ % UNITS) * PT, stage = n % 3;
+#pragma unroll
+    for (int i = 0; i < PER_WAVE; ++i) {
+      const int piece = min(wave + 8 * i, PIECES - 1), r = piece >> 2, q = piece & 3, p = p0 + r;
+      const float2 *src = ((!ZERO_ROWS || p < P) ? Htile + ((int64_t)cc * P + p) * M : Hzero) + q * 128;   // wave-uniform
+#if defined(__HIP_DEVICE_COMPILE__)
+      glds16(src, (unsigned)lane * 16u, lds_base + (unsigned)(stage * STAGE + r * 256 + q * 64) * 16u);
+#else
+      hbuf[stage * STAGE + r * 256 + q * 64 + lane] = *reinterpret_cast<const float4 *>(src + lane * 2);
+#endif
+    }
+  };
+  // N of the counted wait in front of unit n: VMEM operations issued after the pieces of unit n, i.e. the pieces of unit
+  // n+1 and the stores that fell between them; exact for UNITS == 1 (a capsule per unit: the stores of the two previous
+  // capsules), the pieces alone otherwise (stricter than needed when a capsule ended in between: still correct)
+  auto wait_unit = [&](int unit) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (UNITS == 1) {
+      switch (min(unit, 2) * n_stores) {     // the first two capsules have fewer stores behind them
+#define AL_WAIT_CASE(S) case S: wait_vm<PER_WAVE + S>(); break;
+        AL_WAIT_CASE(0) AL_WAIT_CASE(1) AL_WAIT_CASE(2) AL_WAIT_CASE(3) AL_WAIT_CASE(4) AL_WAIT_CASE(5) AL_WAIT_CASE(6)
+        AL_WAIT_CASE(7) AL_WAIT_CASE(8) AL_WAIT_CASE(9) AL_WAIT_CASE(10) AL_WAIT_CASE(11) AL_WAIT_CASE(12) AL_WAIT_CASE(14)
+        AL_WAIT_CASE(16) AL_WAIT_CASE(18) AL_WAIT_CASE(20) AL_WAIT_CASE(22) AL_WAIT_CASE(24)
+#undef AL_WAIT_CASE
+        default: wait_vm<PER_WAVE>(); break;
+      }
+    } else {
+      wait_vm<PER_WAVE>();
+    }
+    __builtin_amdgcn_s_barrier();
+#else
+    __syncthreads();
+#endif
+  };
+  static_assert(KT <= 12, "the counted waits enumerate at most 12 stores per capsule");
+  issue(0);
+  issue(1);
+  int n = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    V acc[KT];
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) acc[kk] = V::zero();
+    static_for<UNITS>([&](auto u_c) {
+      constexpr int u = decltype(u_c)::value;
+      wait_unit(n);                                             // unit n is in stage n % 3; stage (n + 2) % 3 is no longer read
+      issue(n + 2);
+      if (active) {
+        const float4 *hs = hbuf + (n % 3) * STAGE + lane256;
+        float4 hv = hs[0], hn = hv;
+        static_for<PT>([&](auto pp_c) {
+          constexpr int pp = decltype(pp_c)::value;
+          if constexpr (pp + 1 < PT) {
+            hn = hs[(pp + 1) * 256];
+#if defined(__HIP_DEVICE_COMPILE__)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+          }
+          const V h{make_float2(hv.x, hv.y), make_float2(hv.z, hv.w)};
+          static_for<KT>([&](auto kk_c) {
+            constexpr int kk = decltype(kk_c)::value;
+            acc[kk].template fma_packed<BIN0>(window(std::integral_constant<int, kk + (PALL - 1) - (u * PT + pp)>{}), h, packed);
+          });
+          hv = hn;
+        });
+      }
+      ++n;
+    });
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < KT; ++kk)
+        if (kk < n_stores) acc[kk].store(Y + ((int64_t)c * K + kk) * M);
+    }
+  }
+#if defined(__HIP_DEVICE_COMPILE__)
+  wait_vm<0>();   // the two re-fetched units past the end must have landed before the LDS goes back to the next workgroup
+#endif
+}
+
+// ZERO_ROWS: the partition count is not a multiple of UNITS * PT, the missing rows of the last unit come from the all-zero block
+template <int KT, int PT, int UNITS = 1, bool ZERO_ROWS = (UNITS > 1), int NL = 0>
+__global__ __launch_bounds__(512, 2) void k_spectral_mac_static_glds(al_batch b) {
+  __shared__ float4 hbuf[3 * PT * 256];
+  __shared__ float4 xbuf[NL > 0 ? 2 * NL * 512 : 1];
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_glds_body<KT, PT, UNITS, true, ZERO_ROWS, NL>(b, hbuf, xbuf);
+  else spectral_mac_static_glds_body<KT, PT, UNITS, false, ZERO_ROWS, NL>(b, hbuf, xbuf);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events
@@ -1041,7 +1216,8 @@ int check_batch(const al_batch *b) {
 // 3120000 + 100*P + {1: k_spectral_mac_static<12,P,1>, 2: <12,P,2>, 3: k_spectral_mac_static_lds (P <= 12: <12,P,1>,
 // 13..16: <12,ceil(P/2),2>)}; sliding-window kernel k_spectral_mac_moving<6,PT,1> = 600 + PT.
 namespace {
-enum MacStaticKind { MAC_STATIC_NONE = 0, MAC_STATIC_ONE = 1, MAC_STATIC_PAIR = 2, MAC_STATIC_LDS = 3, MAC_STATIC_LDS_UNITS = 4 };
+enum MacStaticKind { MAC_STATIC_NONE = 0, MAC_STATIC_ONE = 1, MAC_STATIC_PAIR = 2, MAC_STATIC_LDS = 3, MAC_STATIC_LDS_UNITS = 4,
+                     MAC_STATIC_GLDS = 5 };
 
 struct MacPlan {
   int static_kind;    // MacStaticKind: which capsule-loop kernel takes the one-emitter events (NONE: the tile kernel does)
@@ -1077,10 +1253,13 @@ MacPlan plan_mac(const al_batch *b) {
     // flags bit 12 (A/B switch): one k-tile per workgroup; bit 13 (A/B switch): register version beyond 24 blocks
     const bool pair = n_ktiles > 1 && !(b->flags & (1 << 12));
     const int n_pairs = (n_ktiles + 1) / 2;
-    if (P > 12) {   // 13..16 partitions: two units of ceil(P/2) per capsule, 17 / 18: three units of 6; always through LDS,
-      const int units = P > 16 ? 3 : 2;   // always two k-tiles per workgroup.  (Three units of 7 / 8 for 19..24 partitions spill 84 /
-                                          // 132 B per lane and lose to the tile kernels: profiles/r03_p24_ab.txt.)
-      m.static_kind = MAC_STATIC_LDS_UNITS;
+    if (P > 12) {
+      // 13..16 partitions: two units of ceil(P/2) per capsule, 17..24: three units of ceil(P/3); always through LDS, always two
+      // k-tiles per workgroup.  Fed by LDS-DMA (k_spectral_mac_static_glds: no staging registers, so the 35-block signal window
+      // of 24 partitions fits; profiles/r03_p24_ab.txt) when the batch has an all-zero block for the rows past an odd count,
+      // else (13..16 only) by the register-staged ring of k_spectral_mac_static_lds.
+      const int units = P > 16 ? 3 : 2;
+      m.static_kind = b->hspec_zero_block >= 0 ? MAC_STATIC_GLDS : MAC_STATIC_LDS_UNITS;
       m.static_pt = (P + units - 1) / units;
       m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
       m.static_threads = 512;
@@ -1100,7 +1279,11 @@ MacPlan plan_mac(const al_batch *b) {
       m.static_grid = dim3(bins / 512, n_ktiles, b->n_events * n_cs);
       m.static_threads = 256;
     }
-    m.static_code = 3120000 + 100 * P + (m.static_kind == MAC_STATIC_ONE ? 1 : m.static_kind == MAC_STATIC_PAIR ? 2 : 3);
+    // flags bit 14 (A/B switch): at most 12 partitions through the LDS-DMA kernel too (2 % slower there than the register /
+    // register-staged versions: the accumulate of short IRs is not short of flight time, profiles/r03_p24_ab.txt)
+    if ((b->flags & (1 << 14)) && (m.static_kind == MAC_STATIC_PAIR || m.static_kind == MAC_STATIC_LDS)) m.static_kind = MAC_STATIC_GLDS;
+    m.static_code = 3120000 + 100 * P + (m.static_kind == MAC_STATIC_ONE ? 1 : m.static_kind == MAC_STATIC_PAIR ? 2 :
+                                         m.static_kind == MAC_STATIC_GLDS ? 4 : 3);
     if (b->flags & AL_FLAG_ONLY_STATIC) m.tile_code = m.moving_code = 0;   // no event is left for the other kernels
   }
   return m;
@@ -1114,6 +1297,9 @@ void launch_mac_static(const MacPlan &m, const al_batch *b, hipStream_t stream) 
       break;
     case MAC_STATIC_PAIR:
       hipLaunchKernelGGL((al::k_spectral_mac_static<12, PT, 2>), m.static_grid, dim3(512), 0, stream, *b);
+      break;
+    case MAC_STATIC_GLDS:
+      hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, PT>), m.static_grid, dim3(512), 0, stream, *b);
       break;
     default:
       hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, PT>), m.static_grid, dim3(512), 0, stream, *b);
@@ -1194,13 +1380,17 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   const MacPlan m = plan_mac(b);
   const int bins = 1 << b->log2_block;
-  if (m.static_kind == MAC_STATIC_LDS_UNITS) {
-    if (b->n_partitions <= 16) {
-      if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
-      else hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
-    } else {
-      hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 6, 3>), m.static_grid, dim3(512), 0, stream, *b);
-    }
+  if (m.static_kind == MAC_STATIC_GLDS && b->n_partitions > 12) {
+    const int P = b->n_partitions;
+    if (P <= 14) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else if (P <= 16) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else if (P <= 18) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 6, 3>), m.static_grid, dim3(512), 0, stream, *b);
+    else if (P <= 21) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 3, true, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 8, 3, true, 3>), m.static_grid, dim3(512), 0, stream, *b);
+    if (int rc = check_launch("k_spectral_mac_static_glds")) return rc;
+  } else if (m.static_kind == MAC_STATIC_LDS_UNITS) {
+    if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
     if (int rc = check_launch("k_spectral_mac_static_lds")) return rc;
   } else if (m.static_kind != MAC_STATIC_NONE) {
     switch (m.static_pt) {   // the partition tile IS the partition count: no masked partitions in the loop

@@ -6,9 +6,11 @@ import numpy as np, torch
 from audiblelight_amd import engine, plan as planning
 r = engine.Renderer()
 rng = np.random.default_rng(0)
-for Lir in (135000, 150000, 170000, 192000):
-    for max_p in ("16", "24"):
-        os.environ["AL_STATIC_MAC_MAX_P"] = max_p
+for Lir in (100000, 125000, 135000, 150000, 170000, 192000):
+    for max_p, flags in (("12", "0"), ("18", "0"), ("24", "16384")):    # tile kernels | register / LDS-staged capsule loop | LDS-DMA capsule loop
+        if max_p == "18" and Lir > 147456:
+            continue
+        os.environ["AL_STATIC_MAC_MAX_P"], os.environ["AL_EXTRA_FLAGS"] = max_p, flags
         C, E, La = 32, 64, 192000
         clips = [rng.standard_normal(La).astype(np.float32) for _ in range(E)]
         irs = (rng.standard_normal((C, E, Lir), dtype=np.float32) * np.exp(-np.arange(Lir) / (Lir / 6.9)).astype(np.float32))

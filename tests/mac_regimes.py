@@ -31,16 +31,25 @@ STATIC_CASES = [
 #  K multiple, P multiple, capsules, events); one event => the capsule loop is split into ranges (small batch)
 _CLIP_REGIMES = (("one_ktile", 9.3, 1), ("two_ktiles", 20.6, 2), ("beyond_24_blocks", 26.3, 3))
 STATIC_LOOP_CASES = [
-    (f"P{P}_{name}", 3120000 + 100 * P + (3 if P > 12 else digit), k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
-    for P in range(1, 19) for name, k_mult, digit in _CLIP_REGIMES]
-STATIC_LOOP_CASES += [   # hand-picked edges kept from round 2
+    (f"P{P}_{name}", 3120000 + 100 * P + (4 if P > 12 else digit), k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
+    for P in range(1, 25) for name, k_mult, digit in _CLIP_REGIMES]
+STATIC_LOOP_CASES += [   # hand-picked edges
     ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
     ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
     ("three_ktiles_idle_half", 3121203, 26.3, 12.0, 2, 1),     # K = 27: 3 k-tiles in 2 workgroups, the last has an idle half
     ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
-    ("two_units_16_long", 3121603, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
-    ("two_units_one_ktile", 3121403, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
+    ("two_units_16_long", 3121604, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
+    ("two_units_one_ktile", 3121404, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
+    ("cfg5_shape", 3122404, 23.44, 23.44, 3, 2),               # K = 24, P = 24: cfg5's tile counts
 ]
+# k_spectral_mac_static_glds<12,P> for at most 12 partitions (AL_EXTRA_FLAGS bit 14: an A/B switch, the default there is the
+# register / register-staged kernel): P = 1..12, clips of 13..24 and of more than 24 blocks
+GLDS_CASES = [(f"glds_P{P}_{name}", 3120000 + 100 * P + 4, k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
+              for P in range(1, 13) for name, k_mult, digit in _CLIP_REGIMES[1:]]
+GLDS_CASES += [("glds_cfg2_shape", 3121204, 23.44, 11.72, 5, 2), ("glds_ragged_second_tile", 3120904, 17.3, 8.6, 3, 2),
+               ("glds_three_ktiles_idle_half", 3121204, 26.3, 12.0, 2, 1)]
+# k_spectral_mac_static_lds<12,{7,8},2>: 13..16 partitions for a caller that gave no all-zero block (hspec_zero_block = -1)
+NO_ZERO_BLOCK_CASES = [(f"no_zero_block_P{P}", 3120000 + 100 * P + 3, 20.6, P - 0.37, 2, 1) for P in (13, 14, 15, 16)]
 MOVING_CODES = [612, 624]       # asserted by test_moving_regimes / test_cfg3_regime_all_rows
 # codes the GPU tests assert beyond the tables above: cfg4's <12,6,2>, cfg5's tile kernel with two full partition tiles
 EXTRA_STATIC_CODES = [3120602, 1121202]
@@ -50,7 +59,7 @@ def codes_of_kernel_symbol(sym: str):
     """Demangled kernel name (``nm -C``) -> the al_spectral_mac_variant codes under which it runs, as (kind, code) pairs."""
     import re
 
-    m = re.search(r"k_spectral_mac(_static_lds|_static|_moving)?<([0-9, a-z]+)>", sym)
+    m = re.search(r"k_spectral_mac(_static_lds|_static_glds|_static|_moving)?<([0-9, a-z]+)>", sym)
     if not m:
         return []
     kind, args = m.group(1) or "", [a.strip() for a in m.group(2).split(",")]
@@ -60,18 +69,23 @@ def codes_of_kernel_symbol(sym: str):
     if kind == "_moving":
         return [("moving", 100 * int(args[0]) + int(args[1]))]
     pt, last = int(args[1]), int(args[2])
+    if kind == "_static_glds":
+        units = int(args[2])
+        return [("static", 3120000 + 100 * p + 4) for p in ([pt] if units == 1 else range(units * (pt - 1) + 1, units * pt + 1))
+                if units < 3 or p > 16]
     if kind == "_static":
         return [("static", 3120000 + 100 * pt + last)]
     if last == 1:
         return [("static", 3120000 + 100 * pt + 3)]
     if last == 2:
         return [("static", 3120000 + 100 * p + 3) for p in (2 * pt - 1, 2 * pt)]   # two units per capsule: P = 2*PT - 1 and 2*PT
-    return [("static", 3120000 + 100 * p + 3) for p in (17, 18)]                   # three units of 6: P = 17, 18
+    raise AssertionError(f"unexpected instantiation {sym}")
 
 
 def asserted_codes():
     """Every (kind, code) some -m gpu test asserts through al_spectral_mac_variant."""
-    out = {("static", c[1]) for c in STATIC_CASES} | {("static", c[1]) for c in STATIC_LOOP_CASES}
+    out = {("static", c[1]) for c in STATIC_CASES} | {("static", c[1]) for c in STATIC_LOOP_CASES} | {("static", c[1]) for c in GLDS_CASES}
+    out |= {("static", c[1]) for c in NO_ZERO_BLOCK_CASES}
     out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES}
     return out
 
@@ -103,7 +117,8 @@ def is_fused(batch, chunk=0):
     return bool(batch.descs[chunk].flags & _hip.FLAG_FUSED_STATIC)
 
 
-def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None, expect_split=None):
+def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None, expect_split=None,
+                    zero_block=True):
     """``expect_fused``: None = whatever the library picks (B = 8192: al_mac_synthesis, csrc/al_fused.h), True / False =
     assert it (callers force the unfused kernels with AL_FUSED=0 so that their dispatch branches stay pinned too)."""
     B = 1 << log2_block
@@ -119,6 +134,9 @@ def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0
     mic_ir = np.concatenate(irs, axis=1)
     pl = planning.plan_batch(specs, C, Lir, 48000, log2_block=log2_block)
     batch = renderer.prepare(pl, clips, mic_ir)
+    if not zero_block:       # a C host that does not provide the all-zero spectrum block
+        for desc in batch.descs:
+            desc.hspec_zero_block = -1
     got_code, moving = mac_codes(renderer, batch)
     assert got_code == code and moving == 0, (got_code, moving)
     if expect_split is not None:

@@ -33,12 +33,33 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
 @pytest.mark.parametrize("log2_block", [10, 13])
 @pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.STATIC_LOOP_CASES, ids=[c[0] for c in mr.STATIC_LOOP_CASES])
 def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
-    """k_spectral_mac_static / _static_lds (default for one-emitter events with at most 16 partitions): EVERY instantiation
-    -- partition counts 1..16 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
+    """k_spectral_mac_static / _static_lds / _static_glds (default for one-emitter events with at most 24 partitions): EVERY
+    instantiation -- partition counts 1..24 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
     the capsule-range split of small batches; every row against the oracle, the instantiation asserted."""
     monkeypatch.delenv("AL_STATIC_MAC", raising=False)
     monkeypatch.delenv("AL_FUSED", raising=False)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
+
+
+@pytest.mark.parametrize("log2_block", [10, 13])
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.GLDS_CASES, ids=[c[0] for c in mr.GLDS_CASES])
+def test_static_capsule_loop_glds_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
+    """k_spectral_mac_static_glds (partition spectra into the LDS ring by LDS-DMA, counted s_waitcnt) for at most 12 partitions,
+    where it is an A/B switch (13..24 partitions take it by default: test_static_capsule_loop_kernel): every partition count
+    1..12, second k-tile full / ragged / idle, one and several workgroups per (event, bin tile); every row against the oracle."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_FUSED", raising=False)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
+
+
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.NO_ZERO_BLOCK_CASES, ids=[c[0] for c in mr.NO_ZERO_BLOCK_CASES])
+def test_static_capsule_loop_without_zero_block(gpu, monkeypatch, name, code, k_mult, p_mult, C, E):
+    """13..16 partitions for a batch without an all-zero spectrum block (hspec_zero_block = -1, e.g. a C host that keeps
+    none): the register-staged two-unit kernel k_spectral_mac_static_lds<12,{7,8},2> instead of the LDS-DMA one."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    mr.run_static_case(gpu, 13, code, k_mult, p_mult, C=C, E=E, zero_block=False)
 
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])

@@ -19,12 +19,21 @@ def test_emu_static_regimes(emu, name, code, k_mult, p_mult, monkeypatch):
 
 
 @pytest.mark.parametrize("code,k_mult,p_mult,C,E", [(3120902, 17.3, 8.6, 3, 1), (3120601, 10.0006, 5.002, 2, 2), (3120301, 6.5, 2.5, 3, 1),
-                                                   (3120503, 25.7, 4.3, 2, 1), (3121303, 14.3, 12.6, 2, 1), (3121703, 13.2, 16.6, 2, 1)])
+                                                   (3120503, 25.7, 4.3, 2, 1), (3121304, 14.3, 12.6, 2, 1), (3121704, 13.2, 16.6, 2, 1), (3122304, 13.2, 22.4, 1, 1)])
 def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeypatch):
     """k_spectral_mac_static under emulation: paired k-tiles with a half-empty second tile and masked partitions, the
     6-partition instantiations, the capsule-range split."""
     monkeypatch.delenv("AL_STATIC_MAC", raising=False)
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=C, E=E)
+
+
+def test_emu_static_glds_kernel(emu, monkeypatch):
+    """k_spectral_mac_static_glds under emulation (the LDS-DMA pieces as plain copies: ring indexing, piece -> row mapping,
+    the repeated last piece where PT * 4 is not a multiple of 8, ragged second k-tile)."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+    mr.run_static_case(emu, 10, 3120904, 17.3, 8.6, C=3, E=1)
+    mr.run_static_case(emu, 10, 3120304, 26.3, 2.5, C=2, E=1)
 
 
 @pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (12.6, 624), (24.2, 0)])

@@ -118,9 +118,10 @@ template <> struct BinVec<2> {
 
 // k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
 __host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
-  // up to 24 partitions through the LDS-DMA kernel (it reads the rows past an odd partition count from the all-zero block),
-  // up to 16 through the register-staged one when the caller gave no zero block
-  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= (b.hspec_zero_block >= 0 ? 24 : 16) && b.log2_block >= 9;
+  // up to 21 partitions through the LDS-DMA kernel (it reads the rows past an odd partition count from the all-zero block),
+  // up to 16 through the register-staged one when the caller gave no zero block.  22..24 stay on the tile kernels: three
+  // units of 8 fit (ends of the 35-block window in LDS) but only tie them at C = 32 and lose 5 % on cfg5 (profiles/r03_p24_ab.txt)
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= (b.hspec_zero_block >= 0 ? 21 : 16) && b.log2_block >= 9;
 }
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
@@ -458,7 +459,7 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 
 // NL: the NL signal blocks at EACH end of the window live in LDS instead of registers.  Block jj of the window meets
 // min(jj + 1, NJ - jj, KT) products per capsule, so the ends are the cheap ones to re-read: NL = 3 costs 12 extra
-// ds_read_b128 per capsule and frees 24 VGPRs, which is what the 35-block window of 22..24 partitions needs to stay
+// ds_read_b128 per capsule and frees 24 VGPRs, which is what the 32-block window of 19..21 partitions (NL = 2) needs to stay
 // out of scratch memory (a spill reload would also drain the LDS-DMA in flight: hipcc waits vmcnt(0) for it).
 template <int KT, int PT, int UNITS, bool BIN0, bool ZERO_ROWS = (UNITS > 1), int NL = 0>
 __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b, float4 *hbuf, float4 *xbuf = nullptr) {
@@ -1254,9 +1255,9 @@ MacPlan plan_mac(const al_batch *b) {
     const bool pair = n_ktiles > 1 && !(b->flags & (1 << 12));
     const int n_pairs = (n_ktiles + 1) / 2;
     if (P > 12) {
-      // 13..16 partitions: two units of ceil(P/2) per capsule, 17..24: three units of ceil(P/3); always through LDS, always two
-      // k-tiles per workgroup.  Fed by LDS-DMA (k_spectral_mac_static_glds: no staging registers, so the 35-block signal window
-      // of 24 partitions fits; profiles/r03_p24_ab.txt) when the batch has an all-zero block for the rows past an odd count,
+      // 13..16 partitions: two units of ceil(P/2) per capsule, 17..21: three units of ceil(P/3); always through LDS, always two
+      // k-tiles per workgroup.  Fed by LDS-DMA (k_spectral_mac_static_glds: no staging registers, so the 32-block signal window
+      // of 21 partitions fits; profiles/r03_p24_ab.txt) when the batch has an all-zero block for the rows past an odd count,
       // else (13..16 only) by the register-staged ring of k_spectral_mac_static_lds.
       const int units = P > 16 ? 3 : 2;
       m.static_kind = b->hspec_zero_block >= 0 ? MAC_STATIC_GLDS : MAC_STATIC_LDS_UNITS;
@@ -1385,8 +1386,7 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
     if (P <= 14) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
     else if (P <= 16) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
     else if (P <= 18) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 6, 3>), m.static_grid, dim3(512), 0, stream, *b);
-    else if (P <= 21) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 3, true, 2>), m.static_grid, dim3(512), 0, stream, *b);
-    else hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 8, 3, true, 3>), m.static_grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 3, true, 2>), m.static_grid, dim3(512), 0, stream, *b);
     if (int rc = check_launch("k_spectral_mac_static_glds")) return rc;
   } else if (m.static_kind == MAC_STATIC_LDS_UNITS) {
     if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);

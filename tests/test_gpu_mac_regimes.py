@@ -33,8 +33,8 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
 @pytest.mark.parametrize("log2_block", [10, 13])
 @pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.STATIC_LOOP_CASES, ids=[c[0] for c in mr.STATIC_LOOP_CASES])
 def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_mult, p_mult, C, E):
-    """k_spectral_mac_static / _static_lds / _static_glds (default for one-emitter events with at most 24 partitions): EVERY
-    instantiation -- partition counts 1..24 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
+    """k_spectral_mac_static / _static_lds / _static_glds (default for one-emitter events with at most 21 partitions): EVERY
+    instantiation -- partition counts 1..21 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
     the capsule-range split of small batches; every row against the oracle, the instantiation asserted."""
     monkeypatch.delenv("AL_STATIC_MAC", raising=False)
     monkeypatch.delenv("AL_FUSED", raising=False)

@@ -19,7 +19,7 @@ def test_emu_static_regimes(emu, name, code, k_mult, p_mult, monkeypatch):
 
 
 @pytest.mark.parametrize("code,k_mult,p_mult,C,E", [(3120902, 17.3, 8.6, 3, 1), (3120601, 10.0006, 5.002, 2, 2), (3120301, 6.5, 2.5, 3, 1),
-                                                   (3120503, 25.7, 4.3, 2, 1), (3121304, 14.3, 12.6, 2, 1), (3121704, 13.2, 16.6, 2, 1), (3122304, 13.2, 22.4, 1, 1)])
+                                                   (3120503, 25.7, 4.3, 2, 1), (3121304, 14.3, 12.6, 2, 1), (3121704, 13.2, 16.6, 2, 1), (3122004, 13.2, 19.4, 1, 1)])
 def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeypatch):
     """k_spectral_mac_static under emulation: paired k-tiles with a half-empty second tile and masked partitions, the
     6-partition instantiations, the capsule-range split."""

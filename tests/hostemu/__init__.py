@@ -18,7 +18,7 @@ def build(sanitize: bool = False) -> str:
         os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):
         return LIB
-    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread"] + (["-fsanitize=address,undefined"] if sanitize else [])
+    flags = ["-std=c++17", "-O2", "-g", "-fPIC", "-pthread"] + (["-DHOSTEMU_THREADS", "-fsanitize=address,undefined"] if sanitize else [])
     objs = [os.path.join(os.path.dirname(LIB), os.path.basename(src) + ".o") for src in SRCS]
     jobs = [subprocess.Popen(["g++"] + flags + ["-x", "c++", "-I", HERE, "-c", src, "-o", obj]) for src, obj in zip(SRCS, objs)]
     if any(job.wait() != 0 for job in jobs):          # the two translation units compile side by side

@@ -27,6 +27,27 @@ def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeyp
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=C, E=E)
 
 
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.STATIC_LOOP_CASES, ids=[c[0] for c in mr.STATIC_LOOP_CASES])
+def test_emu_every_capsule_loop_instantiation(emu, monkeypatch, name, code, k_mult, p_mult, C, E):
+    """The case table the GPU suite runs at B = 8192 and 1024 (partition counts 1..21 x three clip-length regimes + edges), here
+    at B = 1024 on the host-emulated kernels: the index arithmetic of every capsule-loop instantiation is checked on CPU too."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1)
+
+
+@pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.GLDS_CASES[::3] + mr.NO_ZERO_BLOCK_CASES[::3],
+                         ids=[c[0] for c in mr.GLDS_CASES[::3] + mr.NO_ZERO_BLOCK_CASES[::3]])
+def test_emu_glds_switch_and_no_zero_block(emu, monkeypatch, name, code, k_mult, p_mult, C, E):
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    if code % 10 == 4:
+        monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+        mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1)
+    else:
+        monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+        mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1, zero_block=False)
+
+
 def test_emu_static_glds_kernel(emu, monkeypatch):
     """k_spectral_mac_static_glds under emulation (the LDS-DMA pieces as plain copies: ring indexing, piece -> row mapping,
     the repeated last piece where PT * 4 is not a multiple of 8, ragged second k-tile)."""

@@ -461,10 +461,11 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // min(jj + 1, NJ - jj, KT) products per capsule, so the ends are the cheap ones to re-read: NL = 3 costs 12 extra
 // ds_read_b128 per capsule and frees 24 VGPRs, which is what the 32-block window of 19..21 partitions (NL = 2) needs to stay
 // out of scratch memory (a spill reload would also drain the LDS-DMA in flight: hipcc waits vmcnt(0) for it).
-template <int KT, int PT, int UNITS, bool BIN0, bool ZERO_ROWS = (UNITS > 1), int NL = 0>
+template <int KT, int PT, int UNITS, bool BIN0, bool ZERO_ROWS = (UNITS > 1), int NL = 0, int NKTW = 2>
 __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b, float4 *hbuf, float4 *xbuf = nullptr) {
   using V = BinVec<2>;
-  constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PIECES = PT * 4, PER_WAVE = (PIECES + 7) / 8;
+  constexpr int NWAVES = 4 * NKTW;      // NKTW k-tiles of 256 threads per workgroup
+  constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PIECES = PT * 4, PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
   const int M = 1 << b.log2_block;
   const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8, lane = threadIdx.x & 63;
   const int f = (blockIdx.x * 256 + lane256) * 2;
@@ -473,7 +474,7 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
   const al_event ev = b.events[b.event0 + e];
   if (ev.n_streams != 1) return;
   const int K = ev.n_blocks, P = b.n_partitions, C = b.n_capsules;
-  const int k0 = (blockIdx.y * 2 + sub) * KT;
+  const int k0 = (blockIdx.y * NKTW + sub) * KT;
   const bool active = k0 < K;
   const int n_stores = active ? min(KT, K - k0) : 0;            // Y stores this half issues per capsule (workgroup-half uniform)
   const int c_begin = (int)((int64_t)cs * C / n_cs), c_end = (int)((int64_t)(cs + 1) * C / n_cs);
@@ -493,15 +494,15 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
       const int j = jbase + jj;
       V x = V::load(X + (int64_t)min(max(j, jlo), jhi - 1) * M);
       x.scale((j >= jlo && j < jhi) ? g : 0.f);
-      if constexpr (jj < NL) xbuf[jj * 512 + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
-      else if constexpr (jj >= NJ - NL) xbuf[(jj - (NJ - 2 * NL)) * 512 + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
+      if constexpr (jj < NL) xbuf[jj * (256 * NKTW) + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
+      else if constexpr (jj >= NJ - NL) xbuf[(jj - (NJ - 2 * NL)) * (256 * NKTW) + threadIdx.x] = make_float4(x.a.x, x.a.y, x.c.x, x.c.y);
       else xw[jj - NL] = x;
     });
   }
   auto window = [&](auto jj_c) -> V {                          // a thread reads back only what it wrote: no barrier needed
     constexpr int jj = decltype(jj_c)::value;
     if constexpr (jj < NL || jj >= NJ - NL) {
-      const float4 v = xbuf[(jj < NL ? jj : jj - (NJ - 2 * NL)) * 512 + threadIdx.x];
+      const float4 v = xbuf[(jj < NL ? jj : jj - (NJ - 2 * NL)) * (256 * NKTW) + threadIdx.x];
       return V{make_float2(v.x, v.y), make_float2(v.z, v.w)};
     } else {
       return xw[jj - NL];
@@ -520,7 +521,7 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
     const int n_ = min(n, n_units - 1), cc = c_begin + n_ / UNITS, p0 = (n_ % UNITS) * PT, stage = n % 3;
 #pragma unroll
     for (int i = 0; i < PER_WAVE; ++i) {
-      const int piece = min(wave + 8 * i, PIECES - 1), r = piece >> 2, q = piece & 3, p = p0 + r;
+      const int piece = min(wave + NWAVES * i, PIECES - 1), r = piece >> 2, q = piece & 3, p = p0 + r;
       const float2 *src = ((!ZERO_ROWS || p < P) ? Htile + ((int64_t)cc * P + p) * M : Hzero) + q * 128;   // wave-uniform
 #if defined(__HIP_DEVICE_COMPILE__)
       glds16(src, (unsigned)lane * 16u, lds_base + (unsigned)(stage * STAGE + r * 256 + q * 64) * 16u);
@@ -596,12 +597,12 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
 }
 
 // ZERO_ROWS: the partition count is not a multiple of UNITS * PT, the missing rows of the last unit come from the all-zero block
-template <int KT, int PT, int UNITS = 1, bool ZERO_ROWS = (UNITS > 1), int NL = 0>
-__global__ __launch_bounds__(512, 2) void k_spectral_mac_static_glds(al_batch b) {
+template <int KT, int PT, int UNITS = 1, bool ZERO_ROWS = (UNITS > 1), int NL = 0, int NKTW = 2>
+__global__ __launch_bounds__(256 * NKTW, NKTW) void k_spectral_mac_static_glds(al_batch b) {
   __shared__ float4 hbuf[3 * PT * 256];
-  __shared__ float4 xbuf[NL > 0 ? 2 * NL * 512 : 1];
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_glds_body<KT, PT, UNITS, true, ZERO_ROWS, NL>(b, hbuf, xbuf);
-  else spectral_mac_static_glds_body<KT, PT, UNITS, false, ZERO_ROWS, NL>(b, hbuf, xbuf);
+  __shared__ float4 xbuf[NL > 0 ? 2 * NL * 256 * NKTW : 1];
+  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_glds_body<KT, PT, UNITS, true, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf);
+  else spectral_mac_static_glds_body<KT, PT, UNITS, false, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events

@@ -43,3 +43,28 @@ for C_enc, fmt in ((8, _hip.FRAMES_PCM16), (4, _hip.FRAMES_F32), (5, _hip.FRAMES
     out = r.mem.zeros(C_enc * T, np.int16 if fmt == _hip.FRAMES_PCM16 else np.float32)
     r.lib.call("al_encode_frames", r.mem.ptr(scene_in), C_enc, T, fmt, r.mem.ptr(out), r.mem.stream())
 print("asan run ok: round-2 kernels")
+# round 3 kernels: the LDS-DMA capsule loop ran above (13 partitions -> accumulate code ...04; the DMA pieces are plain copies
+# under emulation); here three units of 7 with the window ends in LDS, the device-side normal draws, the seeded noise
+# transform (even and odd length), the per-channel ambience multipliers and the row-wise axpy
+os.environ["AL_SPLIT"] = "0"
+B, C = 1024, 2
+clips = [rng.standard_normal(14 * B + 3).astype(np.float32)]
+irs = (rng.standard_normal((C, 1, 20 * B - 9)) * np.exp(-np.arange(20 * B - 9) / (4.0 * B))).astype(np.float32)
+pl = planning.plan_batch([planning.EventSpec(n_samples=len(clips[0]), n_emitters=1, snr=10.0)], C, irs.shape[2], sr, log2_block=10)
+batch = r.prepare(pl, clips, irs)
+r.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(s_code), ct.byref(m_code))
+res = batch.run()
+res.check_finite()
+print("asan run ok: 20 partitions, accumulate code", s_code.value)
+from audiblelight_amd import ambience as amb, synthesize as syn
+syn.set_renderer(r)
+for beta, n in ((0, 1003), (1, 1000), (1, 1001)):
+    x = amb.powerlaw_psd_gaussian(beta, (3, n), seed=5, rng="device")
+    assert np.isfinite(x).all()
+a = amb.Ambience(3, 0.125, alias="a", noise="pink", sample_rate=sr, rng="device")
+noise, scales = a.noise_and_scales_device(r, (3, 1000))
+scene_buf = r.mem.zeros(3 * 1000)
+r.lib.call("al_axpy_rows", r.mem.ptr(scene_buf), r.mem.ptr(noise), r.mem.ptr(scales), 3, 1000, r.mem.stream())
+assert np.isfinite(r.mem.download(scene_buf)).all()
+syn.set_renderer(None)
+print("asan run ok: round-3 kernels")

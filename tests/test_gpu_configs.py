@@ -377,6 +377,15 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_total"] == 4 * 4 * 240000
     assert out["data"] == "synthetic" and out["value"] > 0 and out["gather"]["ranks_seen"] == [0]
     assert out["timing"]["repeats"] == 3 and out["steps"] == 20
+    # the other two modes on the same backend: a batch of scenes all gathered, one scene with its capsules "sharded" over one rank
+    common = [sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "5", "--repeats", "1", "--cpu-events", "0",
+              "--cpu-workers", "0"]
+    for extra, check in ((["--total-scenes", "3"], lambda o: o["config"]["total_scenes"] == 3 and o["gather"]["bytes_total"] == 3 * 4 * 4 * 240000),
+                         (["--shard", "capsules"], lambda o: o["config"]["capsules_this_rank"] == 4 and o["gather"]["within_tolerance"])):
+        res = subprocess.run(common + extra, env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+        assert out["gather"]["backend"] == "nccl" and out["scaling"] == "strong" and check(out), out
 
 
 def test_float64_irs_host_cast_equals_device_cast(gpu, monkeypatch):

@@ -182,3 +182,36 @@ def run_moving_case(renderer, log2_block, p_mult, n_irs, k_mult, expect_moving, 
                                 duration=specs[e].duration, sr=sr)["spatial"]
         check_event_rows(res, e, want)
     return res
+
+
+def run_random_batch(renderer, seed, log2_block=10):
+    """Seeded random batch over the WHOLE shape space of the accumulate dispatch: 1..26 partitions, clips of 1..60 blocks
+    (ragged, several per batch), 1..5 capsules, static events mixed with moving and zero-emitter ones; every row against
+    the oracle.  Whatever instantiation the library picks for it is what gets checked."""
+    rng = np.random.default_rng(5000 + seed)
+    B = 1 << log2_block
+    sr = 16000
+    C = int(rng.integers(1, 6))
+    Lir = int(rng.integers(1, 26 * B))
+    specs, clips, irs, col = [], [], [], 0
+    for _ in range(int(rng.integers(1, 4))):
+        kind = rng.choice(["static", "static", "static", "moving", "dry"])
+        n_audio = int(rng.integers(1, 60 * B if rng.random() < 0.3 else 26 * B))
+        if kind == "moving":
+            n_audio = max(n_audio, 700)
+        n_emit = {"static": 1, "dry": 0, "moving": int(rng.integers(2, 6))}[kind]
+        a = rng.standard_normal(n_audio).astype(np.float32)
+        clips.append(a / np.abs(a).max())
+        irs.append((rng.standard_normal((C, n_emit, Lir)) * np.exp(-np.arange(Lir) / max(Lir / 5.0, 1.0))).astype(np.float32))
+        specs.append(planning.EventSpec(n_samples=n_audio, n_emitters=n_emit, snr=float(rng.uniform(5, 30)), emitter0=col,
+                                        is_moving=n_emit > 1, duration=n_audio / sr))
+        col += n_emit
+    pl = planning.plan_batch(specs, C, Lir, sr, log2_block=log2_block)
+    batch = renderer.prepare(pl, clips, np.concatenate(irs, axis=1))
+    codes = mac_codes(renderer, batch)
+    res = batch.run()
+    res.check_finite()
+    for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
+        want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)["spatial"]
+        check_event_rows(res, i, want)
+    return codes, pl.n_partitions, int(pl.events["n_blocks"].max())

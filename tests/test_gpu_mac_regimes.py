@@ -184,3 +184,14 @@ def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
     """The same through the experimental k_mac_synthesis (AL_FUSED=1)."""
     monkeypatch.setenv("AL_FUSED", "1")
     mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True, expect_split=False)
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_random_shapes_over_the_whole_dispatch_space(gpu, monkeypatch, seed):
+    """Seeded random batches: 1..26 partitions x clips of up to 60 blocks x static / moving / zero-emitter events mixed in one
+    batch (B = 1024 for two thirds of the seeds, 8192 for the rest), every row against the oracle: the accumulate kernels
+    beside each other as real scenes mix them, not one regime per batch."""
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    monkeypatch.delenv("AL_FUSED", raising=False)
+    mr.run_random_batch(gpu, seed, log2_block=13 if seed % 3 == 2 else 10)

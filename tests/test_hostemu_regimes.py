@@ -76,3 +76,10 @@ def test_emu_split_layout_transforms(emu, monkeypatch):
     monkeypatch.setenv("AL_SPLIT", "1")
     mr.run_static_case(emu, 11, 3120601, 10.0006, 5.002, C=2, E=1, expect_split=True)
     mr.run_moving_case(emu, 11, 4.3, n_irs=10, k_mult=14.2, expect_moving=612, C=1, E=1)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_emu_random_shapes_over_the_whole_dispatch_space(emu, monkeypatch, seed):
+    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    mr.run_random_batch(emu, seed)

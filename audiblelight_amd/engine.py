@@ -47,6 +47,8 @@ class TorchMemory:
         arr = np.ascontiguousarray(arr)
         if arr.dtype.fields is not None:  # structured table -> raw bytes
             arr = arr.view(np.uint8)
+        if not arr.flags.writeable:       # torch refuses to wrap read-only memory silently (cached tables are read-only)
+            arr = arr.copy()
         return self.torch.from_numpy(arr).to(self.device, non_blocking=False)
 
     def upload_tables(self, arrays) -> list:

@@ -98,7 +98,10 @@ def default_rng_mode() -> str:
 
 
 def _seed64(seed) -> int:
-    return (config.SEED if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+    """Key of the device generator.  ``seed=None`` means fresh entropy, as ``np.random.default_rng(None)`` does for the host draws."""
+    if seed is None:
+        return int.from_bytes(os.urandom(8), "little")
+    return int(seed) & 0xFFFFFFFFFFFFFFFF
 
 
 def powerlaw_noise_device(renderer, beta: float, rows: int, samples: int, fmin: float = 0.0,

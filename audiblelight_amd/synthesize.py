@@ -412,6 +412,9 @@ def generate_scene_audio_from_events(scene) -> None:
     from .ambience import Ambience
 
     r = get_renderer()
+    # phase 1: enqueue every microphone's mixdown, statistics and downloads; phase 2: ONE synchronisation for the whole scene
+    queued = []
+    pending = {}
     for mic_alias in scene.state.microphones.keys():
         events = list(scene.events.values())
         srcs = [_device_source(r, ev, mic_alias) for ev in events]
@@ -443,26 +446,31 @@ def generate_scene_audio_from_events(scene) -> None:
             first = False
             _attach_padded(events, idxs, mix, mic_alias, channels, duration)
         # librosa.util.valid_audio (synthesize.py:398,603) from device reductions (a host pass over the scene costs more than
-        # rendering it): the scene's statistics, every pending render's per-event statistics and the scene itself are
-        # downloaded behind ONE synchronisation, the scene's DMA enqueued first so that nothing waits in front of it.
-        pending = {}
+        # rendering it): the scenes' statistics, every pending render's per-event statistics and the scenes themselves are
+        # downloaded behind ONE synchronisation, each scene's DMA enqueued ahead of the small ones so nothing waits in front of it.
         for s_ in srcs:
             held_res = s_[6]
             if held_res is not None and not getattr(held_res, "_finite_ok", False):
                 pending[id(held_res)] = held_res
         scene_stats_dev = r.row_stats(scene_dev, 1, channels * duration)
         if hasattr(r.mem, "download_async"):
-            host_t = r.mem.download_async(scene_dev)
-            stats_t = r.mem.download_async(scene_stats_dev)
-            ev_t = {k: r.mem.download_async(v.event_stats) for k, v in pending.items()}
-            r.mem.synchronize()
-            host, stats = host_t.numpy(), stats_t.numpy().reshape(-1, 4)
-            ev_stats = {k: t.numpy() for k, t in ev_t.items()}
+            fetch = (r.mem.download_async(scene_dev), r.mem.download_async(scene_stats_dev))
+        else:
+            fetch = None
+        queued.append((mic_alias, channels, duration, scene_dev, scene_stats_dev, fetch))
+    if hasattr(r.mem, "download_async"):
+        ev_t = {k: r.mem.download_async(v.event_stats) for k, v in pending.items()}
+        r.mem.synchronize()
+        ev_stats = {k: t.numpy() for k, t in ev_t.items()}
+    else:
+        ev_stats = {k: r.mem.download(v.event_stats) for k, v in pending.items()}
+    for k, res_ in pending.items():
+        res_.check_finite(ev_stats[k][: 4 * len(res_.plan.events)].reshape(-1, 4))
+    for mic_alias, channels, duration, scene_dev, scene_stats_dev, fetch in queued:
+        if fetch is not None:
+            host, stats = fetch[0].numpy(), fetch[1].numpy().reshape(-1, 4)
         else:
             host, stats = r.mem.download(scene_dev), r.mem.download(scene_stats_dev).reshape(-1, 4)
-            ev_stats = {k: r.mem.download(v.event_stats) for k, v in pending.items()}
-        for k, res_ in pending.items():
-            res_.check_finite(ev_stats[k][: 4 * len(res_.plan.events)].reshape(-1, 4))
         if stats[0, 2] > 0 or not np.isfinite(stats[0, 0]):
             raise ValueError("Audio buffer is not finite everywhere")
         host = host[: channels * duration].reshape(channels, duration)

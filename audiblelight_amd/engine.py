@@ -155,6 +155,41 @@ class TorchMemory:
         dev.copy_(src, non_blocking=True)
         return dev, (lambda p=arr.ctypes.data, keep=arr: rt.cudaHostUnregister(p))
 
+    def upload_beside(self, arr: np.ndarray):
+        """A large contiguous host array -> HBM while the calling thread goes on: the device buffer is allocated here, the copy
+        itself is one ``hipMemcpy`` (``hipMemcpyAsync`` + ``hipStreamSynchronize`` on a non-default current stream) made from a helper thread
+        through ctypes (which drops the GIL for the call; ``Tensor.to`` keeps it for a pageable source).  Returns
+        (device buffer, future): the buffer holds the data once ``future.result()`` has returned.  For the one long blocking
+        call of a scene -- 14 ms for cfg2's 0.8 GB pageable IR tensor -- beside the planning and clip packing."""
+        from concurrent.futures import ThreadPoolExecutor
+
+        if getattr(self, "_beside_pool", None) is None:
+            self._beside_pool = ThreadPoolExecutor(1, thread_name_prefix="al-upload")
+            self._hiprt = ct.CDLL("libamdhip64.so")
+            self._hiprt.hipMemcpyAsync.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p]
+            self._hiprt.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
+            self._hiprt.hipStreamSynchronize.argtypes = [ct.c_void_p]
+            self._hiprt.hipSetDevice.argtypes = [ct.c_int]
+        flat = np.ascontiguousarray(arr).reshape(-1)
+        dev = self.torch.empty(flat.size, dtype=getattr(self.torch, flat.dtype.name), device=self.device)
+        if getattr(self, "_beside_stream", None) is None:
+            self._beside_stream = self.torch.cuda.Stream(self.device)
+        self._beside_stream.wait_stream(self.torch.cuda.current_stream(self.device))   # `dev` may be a block just released there
+        side = self._beside_stream.cuda_stream
+        index = self.device.index if self.device.index is not None else self.torch.cuda.current_device()
+
+        def job(keep=flat):
+            rt = self._hiprt
+            # on a stream of its own: a copy on the caller's stream would hold that stream's queue lock for its whole length
+            # and stall the caller's own (small, asynchronous) uploads behind it.  Complete on the host before anything reads it.
+            err = rt.hipSetDevice(index) or rt.hipMemcpyAsync(dev.data_ptr(), keep.ctypes.data, keep.nbytes, 1, side) \
+                or rt.hipStreamSynchronize(side)          # 1 = hipMemcpyHostToDevice
+            if err:
+                raise RuntimeError(f"background upload of {keep.nbytes} bytes failed with HIP error {err}")
+            return dev
+
+        return dev, self._beside_pool.submit(job)
+
     def ptr(self, buf) -> int:
         return buf.data_ptr()
 
@@ -340,7 +375,7 @@ class Renderer:
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                 chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
-                audio_dev=None) -> "PreparedBatch":
+                audio_dev=None, ir_ready=None) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
@@ -429,13 +464,15 @@ class Renderer:
             for desc in descs:
                 self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
             bufs["_clip_tables"] = (pre, mode)
+        if ir_ready is not None:    # a future of TorchMemory.upload_beside: the IR tensor was on its way during all of the above
+            ir_ready.result()
         return PreparedBatch(self, plan, bufs, descs, lanes)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None,
-               normalize_irs: bool = True) -> RenderResult:
+               normalize_irs: bool = True, ir_ready=None) -> RenderResult:
         """prepare + run stages 1-6 for one batch."""
-        return self.prepare(plan, clips, irs, ir_strides, chunk_events, normalize_irs).run(stages)
+        return self.prepare(plan, clips, irs, ir_strides, chunk_events, normalize_irs, ir_ready=ir_ready).run(stages)
 
     def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = (), scene=None) -> "PreparedMix":
         """``scene``: an existing (C*T) device buffer to accumulate into (else a new buffer is made)."""

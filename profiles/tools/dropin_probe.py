@@ -18,4 +18,4 @@ for _ in range(12):
 pr.disable()
 print("per call ms:", [round(t, 1) for t in times])
 print("reserved GB", torch.cuda.memory_reserved() / 1e9, "allocated GB", torch.cuda.memory_allocated() / 1e9)
-pstats.Stats(pr).sort_stats("tottime").print_stats(12)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)

@@ -58,3 +58,39 @@ test_ambience_file_mode_matches_the_reference = scenarios.test_ambience_file_mod
 test_big_batches_chunk_themselves = scenarios.test_big_batches_chunk_themselves
 test_dcase_metadata_matches_the_reference_function = scenarios.test_dcase_metadata_matches_the_reference_function
 test_one_fx_realisation_per_event_across_microphones = scenarios.test_one_fx_realisation_per_event_across_microphones
+
+
+def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, monkeypatch):
+    """render_audio_for_all_scene_events sends float32 (C, N, 4k) IR tensors to HBM from a helper thread
+    (TorchMemory.upload_beside) while it plans: same bits as the inline upload, on the default stream and on another one."""
+    import numpy as np
+    import torch
+
+    from audiblelight_amd import core, engine
+
+    rng = np.random.default_rng(5)
+    sr, n_caps, n_ir = 16000, 4, 4000
+    irs = {"a": rng.standard_normal((n_caps, 3, n_ir)).astype(np.float32) * np.exp(-np.arange(n_ir) / 600.0).astype(np.float32),
+           "b": rng.standard_normal((2, 3, n_ir)).astype(np.float32)}
+    clips = [rng.standard_normal(n).astype(np.float32) for n in (9000, 12000, 5000)]
+
+    def render():
+        sc = core.Scene(2.0, core.StaticIRState(irs), sample_rate=sr, ref_db=-50)
+        for i, clip in enumerate(clips):
+            sc.add_event(core.Event(f"e{i}", clip, sr, snr=5 + i, scene_start=0.1 * i))
+        out = sc.generate()
+        return {k: np.array(v) for k, v in out.items()}
+
+    calls = []
+    real = engine.TorchMemory.upload_beside
+    monkeypatch.setattr(engine.TorchMemory, "upload_beside", lambda self, arr: calls.append(arr.shape) or real(self, arr))
+    beside = render()
+    assert calls == [irs["a"].shape, irs["b"].shape]
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        on_side = render()
+    side.synchronize()
+    monkeypatch.delattr(engine.TorchMemory, "upload_beside")
+    inline = render()
+    for k in irs:
+        assert np.array_equal(beside[k], inline[k]) and np.array_equal(on_side[k], inline[k])

@@ -155,19 +155,22 @@ class TorchMemory:
         dev.copy_(src, non_blocking=True)
         return dev, (lambda p=arr.ctypes.data, keep=arr: rt.cudaHostUnregister(p))
 
-    def upload_beside(self, arr: np.ndarray):
-        """A large contiguous host array -> HBM while the calling thread goes on: the device buffer is allocated here, the copy
-        itself is one ``hipMemcpy`` (``hipMemcpyAsync`` + ``hipStreamSynchronize`` on a non-default current stream) made from a helper thread
-        through ctypes (which drops the GIL for the call; ``Tensor.to`` keeps it for a pageable source).  Returns
-        (device buffer, future): the buffer holds the data once ``future.result()`` has returned.  For the one long blocking
-        call of a scene -- 14 ms for cfg2's 0.8 GB pageable IR tensor -- beside the planning and clip packing."""
+    def _helper(self):
         from concurrent.futures import ThreadPoolExecutor
 
         if getattr(self, "_beside_pool", None) is None:
             self._beside_pool = ThreadPoolExecutor(1, thread_name_prefix="al-upload")
+        return self._beside_pool
+
+    def upload_beside(self, arr: np.ndarray):
+        """A large contiguous host array -> HBM while the calling thread goes on: the device buffer is allocated here, the copy
+        itself is one ``hipMemcpyAsync`` + ``hipStreamSynchronize`` on a stream of its own, made from a helper thread
+        through ctypes (which drops the GIL for the call; ``Tensor.to`` keeps it for a pageable source).  Returns
+        (device buffer, future): the buffer holds the data once ``future.result()`` has returned.  For the one long blocking
+        call of a scene -- 14 ms for cfg2's 0.8 GB pageable IR tensor -- beside the planning and clip packing."""
+        if getattr(self, "_hiprt", None) is None:
             self._hiprt = ct.CDLL("libamdhip64.so")
             self._hiprt.hipMemcpyAsync.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int, ct.c_void_p]
-            self._hiprt.hipMemcpy.argtypes = [ct.c_void_p, ct.c_void_p, ct.c_size_t, ct.c_int]
             self._hiprt.hipStreamSynchronize.argtypes = [ct.c_void_p]
             self._hiprt.hipSetDevice.argtypes = [ct.c_int]
         flat = np.ascontiguousarray(arr).reshape(-1)
@@ -188,7 +191,7 @@ class TorchMemory:
                 raise RuntimeError(f"background upload of {keep.nbytes} bytes failed with HIP error {err}")
             return dev
 
-        return dev, self._beside_pool.submit(job)
+        return dev, self._helper().submit(job)
 
     def ptr(self, buf) -> int:
         return buf.data_ptr()
@@ -212,6 +215,17 @@ class TorchMemory:
 
     def synchronize(self):
         self.torch.cuda.synchronize(self.device)
+
+
+class _Arrival:
+    """A future with a fixed value to hand out once it has completed."""
+
+    def __init__(self, future, value):
+        self.future, self.value = future, value
+
+    def result(self):
+        self.future.result()
+        return self.value
 
 
 _PACK_POOL = None
@@ -333,6 +347,21 @@ class Renderer:
                       self.mem.ptr(dev), c * n, l, lp, self.mem.stream())
         return dev, (n * lp, lp)   # `raw` may be released: the allocator orders its reuse behind the kernel (same stream)
 
+    def upload_irs_beside(self, irs):
+        """Start ``upload_irs`` on the memory provider's helper thread and return at once: an object whose ``result()`` gives
+        ``(device buffer, ir_strides)`` -- pass it to ``prepare`` / ``render`` as ``irs`` -- or None when this tensor has to
+        go the inline way.  Taken for float32 with 4-float rows (the layout the kernels read as it is): one pageable copy
+        through ctypes, 26.9 -> 25.6 ms per cfg2 ``Scene.generate()`` (profiles/r03h_dropin_beside_ab.txt)."""
+        mem = self.mem
+        if not (isinstance(irs, np.ndarray) and irs.ndim == 3 and irs.size > 0 and hasattr(mem, "upload_beside")):
+            return None
+        c, n, l = irs.shape
+        if irs.dtype == np.float32 and l % 4 == 0:
+            dev, arrived = mem.upload_beside(irs)
+            return _Arrival(arrived, (dev, (n * l, l)))
+        return None   # float64: the host-cast pipeline already overlaps cast and DMA; beside the clip packing it is SLOWER
+                      # (29.4 vs 28.0 ms per cfg2 scene, profiles/r03h_dropin_beside_ab.txt); ragged rows: re-pitched by a kernel
+
     def pack_audio(self, plan: BatchPlan, clips: Sequence, out: Optional[np.ndarray] = None) -> np.ndarray:
         """Host clips at their 4-float aligned offsets (device-resident clips are copied in HBM by ``prepare``)."""
         host = np.zeros(plan.audio_floats, dtype=np.float32) if out is None else out
@@ -375,14 +404,15 @@ class Renderer:
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                 chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
-                audio_dev=None, ir_ready=None) -> "PreparedBatch":
+                audio_dev=None) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
         ``lanes``: number of workspaces / HIP streams the chunks alternate over (chunk i runs on lane i % lanes),
         so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another."""
         mem = self.mem
-        if ir_strides is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
+        on_its_way = irs if hasattr(irs, "result") else None      # from upload_irs_beside: waited for below, after the staging
+        if ir_strides is None and on_its_way is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
             irs, ir_strides = self.upload_irs(irs)
         B = plan.block
         if chunk_events is None:
@@ -408,6 +438,8 @@ class Renderer:
             tables += [np.array([src.prescale for src in sources], dtype=np.float32),
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
         tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]
+        if on_its_way is not None:
+            irs, ir_strides = on_its_way.result()
         bufs = dict(
             audio=audio_dev, ir=irs, events=tabs[0], streams=tabs[1], wtab=tabs[2], twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
@@ -464,15 +496,13 @@ class Renderer:
             for desc in descs:
                 self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
             bufs["_clip_tables"] = (pre, mode)
-        if ir_ready is not None:    # a future of TorchMemory.upload_beside: the IR tensor was on its way during all of the above
-            ir_ready.result()
         return PreparedBatch(self, plan, bufs, descs, lanes)
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None,
-               normalize_irs: bool = True, ir_ready=None) -> RenderResult:
+               normalize_irs: bool = True) -> RenderResult:
         """prepare + run stages 1-6 for one batch."""
-        return self.prepare(plan, clips, irs, ir_strides, chunk_events, normalize_irs, ir_ready=ir_ready).run(stages)
+        return self.prepare(plan, clips, irs, ir_strides, chunk_events, normalize_irs).run(stages)
 
     def prepare_mixdown(self, mix: MixPlan, result: RenderResult, ambience: Sequence = (), scene=None) -> "PreparedMix":
         """``scene``: an existing (C*T) device buffer to accumulate into (else a new buffer is made)."""

@@ -362,11 +362,11 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
     # The IR tensors start on their way to HBM first, on a helper thread (the one long blocking call of a scene: 14 ms for
     # cfg2's 0.8 GB of pageable memory); this thread stages the clips and plans the batches meanwhile.
     ir_on_device = {}
-    if hasattr(r.mem, "upload_beside"):
+    if hasattr(r, "upload_irs_beside"):
         for mic_alias, mic_ir in irs.items():
-            if (has_work(mic_alias) and isinstance(mic_ir, np.ndarray) and mic_ir.ndim == 3 and mic_ir.dtype == np.float32
-                    and mic_ir.shape[2] % 4 == 0 and mic_ir.size > 0):      # the layout the kernels read as it is
-                ir_on_device[mic_alias] = r.mem.upload_beside(mic_ir)
+            started = r.upload_irs_beside(mic_ir) if has_work(mic_alias) else None
+            if started is not None:
+                ir_on_device[mic_alias] = started
     for n_mic, (mic_alias, mic_ir) in enumerate(irs.items()):
         # FX chains that have to run on the device: raw clips through one staging arena + one DMA (once per scene; with
         # ignore_cache every microphone draws a fresh realisation, as the reference's per-microphone load_audio does)
@@ -391,11 +391,7 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
         # Only ENQUEUED here: nothing below waits for the GPU.  The finite check of the reference (librosa.util.valid_audio,
         # synthesize.py:603) is made where the results first meet the host: in generate_scene_audio_from_events (one combined
         # download of every statistic of the scene) or on the first read of event.spatial_audio[mic].
-        if mic_alias in ir_on_device:
-            ir_dev, arrived = ir_on_device.pop(mic_alias)
-            res = r.render(pl, clips, ir_dev, (mic_ir.shape[1] * mic_ir.shape[2], mic_ir.shape[2]), ir_ready=arrived)
-        else:
-            res = r.render(pl, clips, mic_ir)
+        res = r.render(pl, clips, ir_on_device.pop(mic_alias, mic_ir))
         for i, (event, em0) in enumerate(todo):
             _publish(event, mic_alias, res, i)
         _dry_batch(r, [(event, mic_ir[:, em0: em0 + len(event), :], i, em0) for i, (event, em0) in enumerate(todo)],

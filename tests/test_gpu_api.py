@@ -61,8 +61,9 @@ test_one_fx_realisation_per_event_across_microphones = scenarios.test_one_fx_rea
 
 
 def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, monkeypatch):
-    """render_audio_for_all_scene_events sends float32 (C, N, 4k) IR tensors to HBM from a helper thread
-    (TorchMemory.upload_beside) while it plans: same bits as the inline upload, on the default stream and on another one."""
+    """render_audio_for_all_scene_events starts the IR tensors on their way to HBM from a helper thread while it plans
+    (Renderer.upload_irs_beside: float32 with 4-float rows as one pageable copy; float64 and ragged rows stay inline): same
+    bits as the inline upload, on the default stream and on another one."""
     import numpy as np
     import torch
 
@@ -71,7 +72,8 @@ def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, m
     rng = np.random.default_rng(5)
     sr, n_caps, n_ir = 16000, 4, 4000
     irs = {"a": rng.standard_normal((n_caps, 3, n_ir)).astype(np.float32) * np.exp(-np.arange(n_ir) / 600.0).astype(np.float32),
-           "b": rng.standard_normal((2, 3, n_ir)).astype(np.float32)}
+           "b": rng.standard_normal((2, 3, n_ir)) * np.exp(-np.arange(n_ir) / 900.0),            # float64, as get_irs() returns
+           "c": rng.standard_normal((2, 3, n_ir - 2)).astype(np.float32)}                         # rows to re-pitch: inline
     clips = [rng.standard_normal(n).astype(np.float32) for n in (9000, 12000, 5000)]
 
     def render():
@@ -82,15 +84,21 @@ def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, m
         return {k: np.array(v) for k, v in out.items()}
 
     calls = []
-    real = engine.TorchMemory.upload_beside
-    monkeypatch.setattr(engine.TorchMemory, "upload_beside", lambda self, arr: calls.append(arr.shape) or real(self, arr))
+    real = engine.Renderer.upload_irs_beside
+
+    def spy(self, arr):
+        started = real(self, arr)
+        calls.append((arr.dtype.name, started is not None))
+        return started
+
+    monkeypatch.setattr(engine.Renderer, "upload_irs_beside", spy)
     beside = render()
-    assert calls == [irs["a"].shape, irs["b"].shape]
+    assert calls == [("float32", True), ("float64", False), ("float32", False)]
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         on_side = render()
     side.synchronize()
-    monkeypatch.delattr(engine.TorchMemory, "upload_beside")
+    monkeypatch.setattr(engine.Renderer, "upload_irs_beside", lambda self, arr: None)
     inline = render()
     for k in irs:
         assert np.array_equal(beside[k], inline[k]) and np.array_equal(on_side[k], inline[k])

@@ -102,3 +102,14 @@ def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, m
     inline = render()
     for k in irs:
         assert np.array_equal(beside[k], inline[k]) and np.array_equal(on_side[k], inline[k])
+
+
+def test_free_bytes_reads_the_allocator_counters(gpu_renderer):
+    """TorchMemory.free_bytes (the budget behind Renderer.auto_chunk_events) = free on the device + cached by torch's allocator."""
+    import torch
+
+    keep = torch.empty(1 << 20, device="cuda")
+    del keep                                      # now a cached, unallocated block
+    free, _ = torch.cuda.mem_get_info()
+    want = free + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
+    assert gpu_renderer.mem.free_bytes() == want and torch.cuda.memory_reserved() > torch.cuda.memory_allocated()

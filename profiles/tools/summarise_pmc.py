@@ -22,13 +22,17 @@ NAMES = {"k_forward_spectra": "al_forward_spectra", "k_ir_spectra": "al_ir_spect
 
 
 def per_kernel(path, counter):
-    acc = collections.defaultdict(list)
+    """Per C-ABI stage: the average dispatch of every DISTINCT kernel the stage launches, summed (al_spectral_mac launches up to
+    three kernels per call -- capsule loop, tile kernel, sliding window; averaging over all of a stage's dispatches would halve
+    the stage's traffic whenever two of them run)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter:
             for k, v in NAMES.items():
                 if k in row["Kernel_Name"]:
-                    acc[v].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in acc.items()}
+                    acc[v][row["Kernel_Name"]].append(float(row["Counter_Value"]))
+                    break
+    return {stage: sum(sum(v) / len(v) for v in kernels.values()) for stage, kernels in acc.items()}
 
 
 def main():

@@ -355,14 +355,18 @@ class Renderer:
     def upload_irs_beside(self, irs):
         """Start ``upload_irs`` on the memory provider's helper thread and return at once: an object whose ``result()`` gives
         ``(device buffer, ir_strides)`` -- pass it to ``prepare`` / ``render`` as ``irs`` -- or None when this tensor has to
-        go the inline way.  Taken for float32 with 4-float rows (the layout the kernels read as it is): one pageable copy
+        go the inline way.  Taken for float32 tensors of 8 MiB and more with 4-float rows (the layout the kernels read as it is): one pageable copy
         through ctypes, 26.9 -> 25.6 ms per cfg2 ``Scene.generate()`` (profiles/r03h_dropin_beside_ab.txt)."""
         mem = self.mem
         if not (isinstance(irs, np.ndarray) and irs.ndim == 3 and irs.size > 0 and hasattr(mem, "upload_beside")):
             return None
         c, n, l = irs.shape
-        if irs.dtype == np.float32 and l % 4 == 0:
-            dev, arrived = mem.upload_beside(irs)
+        if irs.dtype == np.float32 and l % 4 == 0 and irs.nbytes >= int(os.environ.get("AL_BESIDE_MIN_BYTES", 8 << 20)) and not getattr(mem, "_no_beside", False):
+            try:
+                dev, arrived = mem.upload_beside(irs)
+            except (OSError, AttributeError):      # no libamdhip64.so under that name for ctypes: the inline copy is always there
+                mem._no_beside = True
+                return None
             return _Arrival(arrived, (dev, (n * l, l)))
         return None   # float64: the host-cast pipeline already overlaps cast and DMA; beside the clip packing it is SLOWER
                       # (29.4 vs 28.0 ms per cfg2 scene, profiles/r03h_dropin_beside_ab.txt); ragged rows: re-pitched by a kernel

@@ -553,7 +553,12 @@ def _attach_padded(events, idxs, mix, mic_alias, channels, duration) -> None:
         a, b = planning.event_slot(ev.scene_start, ev.scene_end, _sr_of(ev), duration)
         ev._spatial_audio_padded = as_lazy(getattr(ev, "_spatial_audio_padded", None))
 
-        def fetch(ev=ev, a=a, b=b):
+        # the closures live in the event's own dictionaries: a strong reference to the event would be a cycle that keeps the
+        # event -- and through event.spatial_audio the whole render's device buffers -- alive until the garbage collector runs
+        ev_ref = _weak(ev)
+
+        def fetch(ev_ref=ev_ref, a=a, b=b):
+            ev = ev_ref()
             full = np.zeros((channels, duration), dtype=np.float32)
             piece = pad_or_truncate_audio(ev.spatial_audio[mic_alias], b - a)
             full[: piece.shape[0], a:b] += piece
@@ -562,13 +567,24 @@ def _attach_padded(events, idxs, mix, mic_alias, channels, duration) -> None:
         LazyAudioDict.__setitem__(ev._spatial_audio_padded, mic_alias, fetch)
         dry = getattr(ev, "_spatial_audio_dry", None)
         if dry is not None and mic_alias in dry:     # kept lazy like the dry render itself: no download unless somebody reads it
-            def fetch_dry(ev=ev, a=a, b=b):
+            def fetch_dry(ev_ref=ev_ref, a=a, b=b):
+                ev = ev_ref()
                 line = np.zeros(duration, dtype=np.float32)
                 line[a:b] += pad_or_truncate_audio(np.asarray(ev._spatial_audio_dry[mic_alias])[None, :], b - a)[0]
                 return line
 
             ev._spatial_audio_dry_padded = as_lazy(getattr(ev, "_spatial_audio_dry_padded", None))
             LazyAudioDict.__setitem__(ev._spatial_audio_dry_padded, mic_alias, fetch_dry)
+
+
+def _weak(obj):
+    """weakref.ref(obj), or a strong stand-in for objects that cannot be weakly referenced (duck-typed events with __slots__)."""
+    import weakref
+
+    try:
+        return weakref.ref(obj)
+    except TypeError:
+        return lambda: obj
 
 
 def _sr_of(ev):

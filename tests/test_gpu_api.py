@@ -83,6 +83,7 @@ def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, m
         out = sc.generate()
         return {k: np.array(v) for k, v in out.items()}
 
+    monkeypatch.setenv("AL_BESIDE_MIN_BYTES", "0")       # default: tensors of 8 MiB and more
     calls = []
     real = engine.Renderer.upload_irs_beside
 

@@ -675,3 +675,26 @@ def test_one_fx_realisation_per_event_across_microphones():
     assert not np.allclose(unit(clip), unit(raw))             # the warp did something
     ev.clear_audio()                                          # dropping the cache draws a new realisation
     assert ev._last_chain is None
+
+
+def test_a_dropped_scene_frees_its_render_without_the_garbage_collector(golden):
+    """The lazy dictionaries of an event hold closures; none of them may hold the event itself (a cycle would keep the render's
+    device buffers -- gigabytes per scene at production size -- alive until a collector pass happens to run)."""
+    import gc
+    import weakref
+
+    scene = build_g8_scene(golden)                      # static + moving + dry-path events, an ambience
+    scene.generate()
+    ev = next(iter(scene.events.values()))
+    held = ev.spatial_audio.device_source("mic000")[0]  # the RenderResult behind event.spatial_audio
+    last = list(scene.events.values())[-1]
+    assert last._spatial_audio_padded["mic000"].shape == scene.audio["mic000"].shape    # the lazies work through weak references
+    del last
+    probes = [weakref.ref(held), weakref.ref(ev), weakref.ref(scene)]
+    gc.collect()
+    gc.disable()
+    try:
+        del scene, ev, held
+        assert [p() for p in probes] == [None, None, None]
+    finally:
+        gc.enable()

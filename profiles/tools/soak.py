@@ -6,6 +6,8 @@ import numpy as np, torch, shutil
 import render_dataset as ex
 from audiblelight_amd import batch as B, engine, synthetic
 out = "/tmp/soak_out"; shutil.rmtree(out, ignore_errors=True)
+if os.environ.get("SOAK_NO_GC") == "1":     # device buffers must come back by reference count alone
+    import gc; gc.disable(); print("garbage collector disabled", flush=True)
 drv = B.BatchDriver()
 def mem(): return round(torch.cuda.memory_reserved() / 1e9, 2), round(resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1e6, 2)
 for rnd in range(4):

@@ -94,7 +94,8 @@ class BatchDriver:
         self.zero_copy_d2h = os.environ.get("AL_D2H", "dma") == "kernel"
         self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
         # threads that cast float64 IR tensors to float32 in the planner stage (0: upload the float64 bytes, cast on the device)
-        self.cast_threads = int(os.environ.get("AL_CONVERT_THREADS", "8")) if os.environ.get("AL_F64_UPLOAD", "host") == "host" else 0
+        # 16: 17.2-19.1 ms per cfg2 scene against 19.5-27.8 with 8 and 16.0 for float32 IRs (profiles/r03i_f64_threads_ab.txt)
+        self.cast_threads = int(os.environ.get("AL_CONVERT_THREADS", "16")) if os.environ.get("AL_F64_UPLOAD", "host") == "host" else 0
         self._cast_pool = None
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
@@ -128,7 +129,7 @@ class BatchDriver:
         if job.irs.dtype == np.float64 and self.cast_threads > 0 and job.irs.size:
             # float64 IRs (the reference's get_irs() dtype): cast HERE, in the planner thread's time, by a pool of threads into
             # the slot's page-locked float32 buffer; the uploader then moves half the bytes, as one asynchronous DMA.  The cast
-            # (11 ms for cfg2) runs beside the upload of the previous scene (14 ms) instead of doubling it.
+            # (11 ms for cfg2 alone, more beside the DMAs) runs beside the upload of the previous scene (14 ms) instead of doubling it.
             if self._cast_pool is None:
                 from concurrent.futures import ThreadPoolExecutor
 

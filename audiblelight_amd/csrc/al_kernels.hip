@@ -650,14 +650,18 @@ __device__ __forceinline__ void spectral_mac_moving_body(const al_batch &b, int4
         acc[W - 1] = V::zero();
         ++kbase;
       }
+      // partitions of this IR that reach a block the event keeps (pad_or_truncate, synthesize.py:590, drops everything from
+      // block K on): partition p of a stream that starts at block j_lo only feeds blocks >= j_lo + p.  The others are not read.
+      const int pl = min(P, K - jlo);
+      if (pl <= 0) continue;
       const float g = gains[l];
       const float2 *hp = H + (((int64_t)t.z * b.n_capsules + c) * P) * M + f;
       const float2 *xp = X + (int64_t)t.w * M + f;
       V h[PT], x[NJW];
 #pragma unroll
       for (int pp = 0; pp < PT; ++pp) {
-        h[pp] = V::load(hp + (int64_t)min(pp, P - 1) * M);
-        h[pp].scale(pp < P ? g : 0.f);
+        h[pp] = V::load(hp + (int64_t)min(pp, pl - 1) * M);
+        h[pp].scale(pp < pl ? g : 0.f);
       }
 #pragma unroll
       for (int jj = 0; jj < NJW; ++jj) {

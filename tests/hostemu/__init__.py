@@ -13,7 +13,16 @@ SRCS = [os.path.join(CSRC, "al_kernels.hip"), os.path.join(CSRC, "al_transforms.
 
 
 def build(sanitize: bool = False) -> str:
+    """Compile the kernel sources for the host (once per source change); pytest-xdist workers take turns behind a file lock."""
+    import fcntl
+
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
+    with open(os.path.join(os.path.dirname(LIB), ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        return _build_locked(sanitize)
+
+
+def _build_locked(sanitize: bool) -> str:
     deps = SRCS + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [
         os.path.join(ROOT, "include", "audiblelight_hip.h"), os.path.join(HERE, "hip", "hip_runtime.h")]
     if os.path.exists(LIB) and all(os.path.getmtime(LIB) > os.path.getmtime(d) for d in deps):

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
-ABI_VERSION = 3   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
+ABI_VERSION = 4   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
 FLAG_FUSED_STATIC = 2
@@ -59,7 +59,7 @@ class AlBatch(_Versioned):
         ("ir_energy", ct.c_void_p), ("emitter_gain", ct.c_void_p), ("hspec", ct.c_void_p), ("xspec", ct.c_void_p),
         ("yspec", ct.c_void_p), ("spatial", ct.c_void_p), ("partials", ct.c_void_p), ("event_stats", ct.c_void_p),
         ("event_scale", ct.c_void_p), ("clip_scale", ct.c_void_p),
-        ("xspec_zero_block", ct.c_int32), ("hspec_zero_block", ct.c_int32),
+        ("xspec_zero_block", ct.c_int32), ("hspec_zero_block", ct.c_int32), ("emitter_parts", ct.c_void_p),
     ]
 
 

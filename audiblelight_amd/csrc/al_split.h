@@ -98,6 +98,12 @@ __device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 
     energy = fmaf(a[i].y, a[i].y, energy);
   }
   const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;             // global (energy partials)
+  if (b.emitter_parts && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS && p >= b.emitter_parts[n]) {   // workgroup-uniform: no kept block hears it
+    float mx = 0.f, zz = 0.f;                         // (al_batch.emitter_parts); its energy still counts for normalize_irs
+    block_reduce3(energy, mx, zz, red, tid, T);
+    if (tid == 0) b.ir_energy[blk] = energy;
+    return;
+  }
   const int64_t hblk = ((int64_t)nz * b.n_capsules + c) * b.n_partitions + p;           // chunk-local spectrum
   float2 *out = reinterpret_cast<float2 *>(b.hspec) + hblk * B;
   {   // odd half first: the second half of the window is zero, so d = s = h and `a` stays for the even half

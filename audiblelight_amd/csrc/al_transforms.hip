@@ -65,9 +65,16 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_ir_spe
 #pragma unroll
     for (int m = H; m < E; ++m) v[m] = make_float2(0.f, 0.f);
     if (p + 1 < p1) load_partition<G>(ir + (int64_t)(p + 1) * M, b.ir_len - (p + 1) * M, tid, nxt);
+    const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;  // global (energy partials)
+    if (b.emitter_parts && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS && p >= b.emitter_parts[n]) {   // workgroup-uniform: energy only
+      float mx = 0.f, z = 0.f;
+      block_reduce3(energy, mx, z, red, tid, T);
+      if (tid == 0) b.ir_energy[blk] = energy;
+      __syncthreads();
+      continue;
+    }
 
     fft_regs_to_regs<G, -1>(v, s, tw, tid);
-    const int64_t blk = ((int64_t)n * b.n_capsules + c) * b.n_partitions + p;  // global (energy partials)
     const int64_t hblk = ((int64_t)blockIdx.z * b.n_capsules + c) * b.n_partitions + p;  // chunk-local spectrum
     real_unpack_store_regs<G>(v, s, tw.w0, tid, reinterpret_cast<float2 *>(b.hspec) + hblk * M);
     __syncthreads();  // LDS image and `red` are reused below and by the next partition

@@ -446,7 +446,11 @@ class Renderer:
         if fold:
             tables += [np.array([src.prescale for src in sources], dtype=np.float32),
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
+        parts = plan.emitter_parts() if os.environ.get("AL_TRIM_PARTITIONS", "1") == "1" else None
+        if parts is not None:        # al_batch.emitter_parts: IR partitions that cannot reach a kept block are not transformed
+            tables.append(parts)
         tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]
+        parts_dev = tabs.pop() if parts is not None else None
         if on_its_way is not None:
             irs, ir_strides = on_its_way.result()
         bufs = dict(
@@ -459,6 +463,8 @@ class Renderer:
             event_scale=mem.empty(len(plan.events)))
         if fold:
             bufs["clip_scale"] = mem.empty(len(plan.events))
+        if parts_dev is not None:
+            bufs["emitter_parts"] = parts_dev
         ptrs = {k: mem.ptr(v) for k, v in bufs.items()}
         extra = [dict(hspec=mem.empty((h_blocks + 1) * B * 2), xspec=mem.empty((x_blocks + 1) * B * 2),
                       yspec=mem.empty(y_blocks * B * 2)) for _ in range(lanes - 1)]

@@ -17,6 +17,7 @@ from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
 
 
 SPARSE_MAX_NJ = 6  # AL_SPARSE_MAX_NJ of include/audiblelight_hip.h
+SPARSE_MAX_PARTITIONS = 24  # AL_SPARSE_MAX_PARTITIONS: beyond it flagged events go through the tile accumulate, which reads every partition
 
 
 def _round_up(x: int, m: int) -> int:
@@ -89,6 +90,27 @@ class BatchPlan:
     @property
     def hspec_blocks(self) -> int:
         return self.n_emitters * self.n_capsules * self.n_partitions
+
+    def emitter_parts(self) -> Optional[np.ndarray]:
+        """al_batch.emitter_parts: per IR column, how many leading partitions can reach a block its event keeps (None: every
+        partition of every IR).  pad_or_truncate_audio (synthesize.py:590) drops the convolution's tail from block n_blocks
+        on, and partition p of an IR whose signal starts at block j_lo only feeds blocks >= j_lo + p.  Only the IRs of
+        sliding-window moving events (al_event.reserved == 1: the one accumulate that honours it) get fewer than P; a
+        column shared by several streams keeps the largest demand."""
+        P = self.n_partitions
+        if (P <= 1 or P > SPARSE_MAX_PARTITIONS or not len(self.streams) or not len(self.events)
+                or not (self.events["reserved"] == 1).any()):
+            return None
+        st, ev = self.streams, self.events
+        real = (ev["n_streams"][st["event"]] > 0) & (st["emitter"] >= 0) & (st["emitter"] < self.n_emitters)
+        reach = np.clip(ev["n_blocks"][st["event"]] - st["j_lo"], 0, P)
+        want = np.where(ev["reserved"][st["event"]] == 1, np.where(st["n_j"] > 0, reach, 0), P).astype(np.int32)
+        need = np.zeros(self.n_emitters, dtype=np.int32)
+        np.maximum.at(need, st["emitter"][real], want[real])
+        unused = np.ones(self.n_emitters, dtype=bool)
+        unused[st["emitter"][real]] = False
+        need[unused] = P
+        return need if (need < P).any() else None
 
     @property
     def max_blocks(self) -> int:

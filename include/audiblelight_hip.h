@@ -27,8 +27,9 @@ extern "C" {
 /* Version of THIS header's struct layouts and entry points.  al_abi_version() returns the value the library was built
  * with; a host must compare it with the AL_ABI_VERSION it was compiled against before passing any struct (al_batch and
  * al_mix grew fields in version 2: clip_scale, xspec/hspec_zero_block, ambience, ambience_scale; version 3 puts
- * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread). */
-#define AL_ABI_VERSION 3
+ * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread;
+ * version 4 appends al_batch.emitter_parts). */
+#define AL_ABI_VERSION 4
 
 #define AL_OK 0
 #define AL_E_BADARG (-1)
@@ -143,6 +144,14 @@ typedef struct {
                               the clip's peak never travels to the host.  Indexed globally like event_scale. */
   int32_t xspec_zero_block; /* index of an all-zero block inside xspec / hspec (-1: none).  al_mac_synthesis reads */
   int32_t hspec_zero_block; /* out-of-range signal blocks / partitions from them instead of masking per lane. */
+  const int32_t *emitter_parts; /* optional (NULL = n_partitions everywhere), indexed globally by IR column: how many leading
+                                   partitions of that IR can reach a block some event keeps.  pad_or_truncate_audio
+                                   (synthesize.py:590) drops everything from block n_blocks on, and partition p of an IR whose
+                                   signal starts at block j_lo only feeds blocks >= j_lo + p; al_forward_spectra / al_ir_spectra
+                                   still read the later partitions (normalize_irs needs their energy) but neither transform nor
+                                   store them, and the sliding-window accumulate never reads them.  Must be n_partitions for
+                                   the IR of every event that is not a sliding-window (al_event.reserved == 1) event; ignored when n_partitions >
+                                   AL_SPARSE_MAX_PARTITIONS (those events then go through the tile accumulate). */
 } al_batch;
 
 /* Mixdown of one microphone (generate_scene_audio_from_events, synthesize.py:314-401). */

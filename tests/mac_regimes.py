@@ -175,8 +175,22 @@ def run_moving_case(renderer, log2_block, p_mult, n_irs, k_mult, expect_moving, 
     assert moving == expect_moving, moving
     if expect_moving:
         assert all(int(r) == 1 for r in pl.events["reserved"]), "planner did not flag the events for the sliding window"
+        # al_batch.emitter_parts: partitions that only reach blocks past the clip's end are neither transformed nor read.  The
+        # spectra workspace is poisoned first, so a read of a block that was not written would turn the event into NaNs.
+        parts = pl.emitter_parts()
+        assert parts is not None and 0 <= parts.min() < pl.n_partitions and parts.max() <= pl.n_partitions
+        assert batch.descs[0].emitter_parts, "the planner's table did not reach the descriptor"
+        n_real = pl.hspec_blocks * B * 2
+        batch.bufs["hspec"][:n_real] = float("nan")
+    else:
+        assert pl.emitter_parts() is None and not batch.descs[0].emitter_parts
     res = batch.run()
     res.check_finite()
+    if expect_moving:   # ... and the transform really left those blocks alone: exactly the trimmed ones still hold the poison
+        h = np.asarray(renderer.mem.download(batch.bufs["hspec"]))[:n_real].reshape(pl.n_emitters, C, pl.n_partitions, 2 * B)
+        untouched = np.isnan(h).all(axis=3)
+        expected = np.arange(pl.n_partitions)[None, None, :] >= parts[:, None, None]
+        assert np.array_equal(untouched, np.broadcast_to(expected, untouched.shape)) and not np.isnan(h[~untouched]).any()
     for e in range(E):
         want = orc.render_event(clips[e], irs[e].astype(np.float64), specs[e].snr, is_moving=True,
                                 duration=specs[e].duration, sr=sr)["spatial"]

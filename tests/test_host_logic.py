@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "audiblelight_hip.h")).read()
     declared = set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
-    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 3
+    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 4
     assert lib.call("al_twiddle_bytes", 13) == 8 * 8192 and lib.call("al_twiddle_bytes", 9) == -1
     assert lib.call("al_row_stats_partials", 3, 40000) == 4 * 3 * 3
     assert lib.call("al_noise_workspace_floats", 2, 1000) > 0
@@ -44,10 +44,10 @@ def test_cabi_library_exports_every_declared_symbol():
 
 def test_struct_layouts_match_the_header():
     assert _hip.EVENT_DTYPE.itemsize == 56 and _hip.STREAM_DTYPE.itemsize == 32
-    assert ct.sizeof(_hip.AlBatch) == 2 * 4 + 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4   # head, ..., 16 pointers, the two zero-block indices
+    assert ct.sizeof(_hip.AlBatch) == 2 * 4 + 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4 + 8   # head, ..., 16 pointers, the two zero-block indices, emitter_parts
     assert ct.sizeof(_hip.AlMix) == 2 * 4 + 6 * 4 + 13 * 8
     b, m = _hip.AlBatch(log2_block=13), _hip.AlMix()
-    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (224, 3, 136, 3)
+    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (232, 4, 136, 4)
     assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
 
 

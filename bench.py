@@ -47,42 +47,102 @@ def cpu_model() -> str:
     return "unknown"
 
 
-def _cpu_worker(job):
-    """One event through the oracle in a worker process (all-cores leg of the CPU baseline)."""
+def physical_cores():
+    """(usable physical cores, how that was found).  The CPUs this process may run on (cgroup / affinity mask, not the machine's
+    count) divided by the SMT width the kernel reports for cpu0 (thread_siblings_list)."""
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = os.cpu_count() or 1
+    smt, how = 1, "no SMT information: every usable CPU counted as a core"
+    try:
+        with open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list") as fh:
+            sib = fh.read().strip()
+        n = 0
+        for part in sib.split(","):
+            lo, _, hi = part.partition("-")
+            n += (int(hi) - int(lo) + 1) if hi else 1
+        smt = max(n, 1)
+        how = f"{usable} usable CPUs (sched_getaffinity) / {smt} hardware threads per core (cpu0 thread_siblings_list = {sib})"
+    except (OSError, ValueError):
+        pass
+    return max(usable // smt, 1), how
+
+
+def under_profiler() -> bool:
+    """rocprofv3 (or any tool that preloads a library which initialises the GPU before main() runs): a process in that state
+    must not start children -- on this pool an exec from a GPU-initialised process takes the machine down."""
+    env = os.environ
+    return ("rocprof" in env.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_TOOL", "ROCPROFILER")) for k in env)
+            or "rocprofiler" in env.get("HSA_TOOLS_LIB", "").lower())
+
+
+def _cpu_scene_worker(job):
+    """ONE whole scene through the oracle in a worker process, the way the reference runs it (synthesize.py:613-677 then
+    :314-401): every event rendered, added into the float32 scene buffer, and the reference's per-event full-scene padded copy
+    (:381-383) built and dropped.  Input generation is outside the timing.  max_events / n_irs_cap bound the sample for the
+    configurations whose full scene takes a core minutes or hours (cfg3, cfg5): then the time is scaled in events x IRs."""
+    config, index, scale, max_events, n_irs_cap = job
+    from audiblelight_amd import synthetic
     from oracle import synth_oracle as orc
 
-    clip, h, snr, ref_db, moving, duration, sr = job
+    over = {"E": max_events} if max_events else {}
+    sc = synthetic.make_scene(config, scene_index=index, scale=scale, **over)
+    gains = sc.gain_db
     t0 = time.perf_counter()
-    orc.render_event(clip, h, snr, ref_db, moving, duration, sr)
-    return time.perf_counter() - t0
+    n_scene = round(sc.duration * sc.sr)
+    scene = np.zeros((sc.n_capsules, n_scene), dtype=np.float32)
+    work = 0
+    for i, sp in enumerate(sc.specs):
+        n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
+        h = sc.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
+        clip = sc.clips[i]
+        if gains is not None:
+            clip = orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(clip, gains[i]))).astype(np.float32)
+        x = orc.render_event(clip, h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, sc.sr)["spatial"]
+        a, b = orc.event_slot(sc.starts[i], sc.ends[i], sc.sr, n_scene)
+        if b > a:
+            piece = orc.fit_length(x, b - a)
+            scene[:, a:b] += piece
+            padded = np.zeros_like(scene)            # event._spatial_audio_padded[mic]
+            padded[:, a:b] += piece
+            del padded
+        work += max(n_used, 1)
+    orc.check_audio(scene)
+    return time.perf_counter() - t0, work
 
 
-def cpu_baseline_all_cores(scene, workers: int, n_irs_cap: int = 8):
-    """the oracle on `workers` host processes, one event each (events are independent, so a
-    scene's events spread over the cores); rate = workers events per wall time, scaled to the scene's event count."""
+def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, n_irs_cap=8):
+    """the oracle on every physical core of the host, ONE PROCESS PER SCENE (scenes are independent; the
+    reference's dataset loop is serial, scripts/generate/benchmark.py:44-77): `workers` different scenes rendered at once,
+    mixdown and per-event padded copies included.  rate = scenes x scene seconds / wall time of the slowest worker."""
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
 
-    jobs, work, full = [], 0, 0
-    for i in range(workers):
-        sp = scene.specs[i % len(scene.specs)]
-        n_used = min(sp.n_emitters, n_irs_cap) if sp.is_moving else sp.n_emitters
-        h = scene.irs[:, sp.emitter0: sp.emitter0 + n_used, :].astype(np.float64)
-        jobs.append((oracle_clip(scene, i % len(scene.clips)), h, sp.snr, sp.ref_db, sp.is_moving, sp.duration, scene.sr))
-        work += max(n_used, 1)
-    for sp in scene.specs:
-        full += max(sp.n_emitters, 1)
-    # spawn, not fork: this process has initialised the GPU; a broken worker raises instead of hanging
+    from audiblelight_amd import synthetic
+
+    cfg = synthetic.CONFIGS[config]
+    max_events = {"cfg3": 1, "cfg5": 2}.get(config, 0)
+    duration = cfg["T"] * scale
+    jobs = [(config, 10_000 + i, scale, max_events, n_irs_cap) for i in range(workers)]
+    # spawn, not fork: a broken worker raises instead of hanging.  Started BEFORE this process initialises the GPU.
     with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:
-        list(pool.map(_cpu_worker, jobs))               # warm: imports, page faults
         t0 = time.perf_counter()
-        list(pool.map(_cpu_worker, jobs))
-        wall = time.perf_counter() - t0
-    total = wall * full / work
-    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=workers, host_cores=os.cpu_count(), kind="port",
-                cpu_model=cpu_model(), extrapolated=True,
-                sample=f"{workers} events of one {scene.name} scene rendered concurrently, one oracle process each "
-                       f"({wall:.1f} s wall), scaled linearly to the scene's events x IRs; mixdown not included")
+        results = list(pool.map(_cpu_scene_worker, jobs))
+        wall_with_inputs = time.perf_counter() - t0
+    slowest = max(t for t, _ in results)
+    sample_work = results[0][1]
+    extrapolated = sample_work < full_work
+    per_scene_s = slowest * full_work / max(sample_work, 1)
+    return dict(value=workers * duration / per_scene_s, unit="scene-seconds/s", cores=workers, host_cpus=os.cpu_count(), kind="port",
+                cpu_model=cpu_model(), core_count_from=how, extrapolated=extrapolated,
+                seconds_per_scene_per_core=[round(min(t for t, _ in results), 2), round(slowest, 2)],
+                wall_s_including_input_generation=round(wall_with_inputs, 1),
+                sample=f"{workers} different {config} scenes at once, one oracle process per scene on one physical core each: "
+                       + (f"all {full_events} events" if not extrapolated else
+                          f"{max_events} of {full_events} events" + (f" with {n_irs_cap} IRs each" if config == "cfg3" else "")
+                          + ", scaled linearly in events x IRs")
+                       + " + float32 mixdown + the reference's per-event padded copies; rate from the slowest worker")
 
 
 def oracle_clip(scene, i):
@@ -300,7 +360,8 @@ def main():
                     help="events timed for the CPU baseline (0 = skip; default: the whole scene for cfg2 = 18 s on one core, "
                          "a bounded sample for the larger configurations)")
     ap.add_argument("--cpu-workers", type=int, default=-1, metavar="N",
-                    help="also time the oracle on N host processes at once (all-cores CPU figure; -1 = one per core, max 64; 0 = skip)")
+                    help="also time the oracle on N host processes at once, one whole scene each (all-cores CPU figure; -1 = one per "
+                         "PHYSICAL core, bounded by free memory; 0 = skip; skipped by itself under a profiler)")
     ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
                     help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; "
                          "default 16 on one GPU, 0 otherwise)")
@@ -334,13 +395,29 @@ def main():
     emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements
 
     # SURVEY 8d (ii), the all-cores CPU figure: its worker processes are started HERE, before this process initialises the
-    # GPU (a GPU-initialised process must not be the parent of an exec on this pool), on the very scene the GPU renders
+    # GPU (a GPU-initialised process must not be the parent of an exec on this pool).  Under a profiler the preloaded tool
+    # library has ALREADY initialised the GPU when main() starts: the leg is skipped and the JSON says so.
     all_cores = None
     if rank == 0 and world == 1 and plain and args.cpu_workers != 0 and not emulate:
-        from audiblelight_amd import synthetic
+        if under_profiler():
+            all_cores = {"skipped": "profiler preload detected (LD_PRELOAD / ROCPROF* / ROCP_TOOL*): this process already holds "
+                                    "the GPU, so it must not start worker processes"}
+        else:
+            from audiblelight_amd import synthetic
 
-        workers = min(os.cpu_count() or 1, 64) if args.cpu_workers < 0 else args.cpu_workers
-        all_cores = cpu_baseline_all_cores(synthetic.make_scene(args.config, scene_index=rank, scale=args.scale), workers)
+            cores, how = physical_cores()
+            workers = cores if args.cpu_workers < 0 else args.cpu_workers
+            cfg = synthetic.CONFIGS[args.config]
+            try:   # every worker holds one scene's IR tensor, three scene-sized buffers and one event's float64 temporaries:
+                   # stay inside half the free memory (a box that runs out of memory dies without a message)
+                avail = next(int(ln.split()[1]) * 1024 for ln in open("/proc/meminfo") if ln.startswith("MemAvailable"))
+                e_eff = {"cfg3": 1, "cfg5": 2}.get(args.config, cfg["E"])
+                per = args.scale * (cfg["C"] * e_eff * cfg["N"] * cfg["Lir"] * 4 + cfg["C"] * cfg["N"] * cfg["Lir"] * 8
+                                    + 3 * cfg["C"] * cfg["T"] * cfg["sr"] * 4 + cfg["C"] * (cfg["La"] + cfg["Lir"]) * 60) + 5e8
+                workers = max(1, min(workers, int(0.5 * avail / per)))
+            except (OSError, StopIteration, ValueError):
+                pass
+            all_cores = cpu_baseline_all_cores(args.config, args.scale, workers, how, cfg["E"], cfg["E"] * cfg["N"])
 
     import torch
 

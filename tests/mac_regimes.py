@@ -10,7 +10,7 @@ import numpy as np
 
 from audiblelight_amd import plan as planning
 from oracle import synth_oracle as orc
-from tests.conftest import rel_rms
+from tests.conftest import assert_parity, rel_rms
 
 TOL = 1e-4
 
@@ -101,8 +101,8 @@ def check_event_rows(res, i, want, tol=TOL):
     got = res.spatial_audio(i)
     assert got.shape == want.shape
     for c in range(want.shape[0]):
-        assert rel_rms(got[c], want[c]) <= tol, (i, c)
-    assert np.max(np.abs(got - want)) <= 10 * tol * np.max(np.abs(want))
+        assert_parity(got[c], want[c], tol, what=(i, c))
+    assert_parity(got, want, tol, what=i)
 
 
 def is_split(batch, chunk=0):

@@ -12,7 +12,7 @@ import pytest
 
 from audiblelight_amd import _hip, dropin, engine, synthesize as ours
 from tests import hostemu
-from tests.conftest import rel_rms
+from tests.conftest import assert_parity
 
 REF = "/root/reference"
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "audiblelight")), reason="reference tree not present")
@@ -60,7 +60,7 @@ def test_install_rebinds_what_scene_generate_imports(reference_synthesize, golde
         ref_syn.render_audio_for_all_scene_events(scene)
         ref_syn.generate_scene_audio_from_events(scene)
         assert scene.audio["mic000"].dtype == np.float32
-        assert rel_rms(scene.audio["mic000"], golden["g8_scene"]) < 1e-4
+        assert_parity(scene.audio["mic000"], golden["g8_scene"], 1e-4)
         # scalar helpers keep the reference's results (its own implementation is the check here)
         x = np.linspace(-0.5, 0.7, 101)
         np.testing.assert_allclose(ref_syn.apply_snr(x, 7.0), originals["apply_snr"](x, 7.0), rtol=1e-6)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 from oracle import synth_oracle as orc
-from tests.conftest import rel_rms
+from tests.conftest import assert_parity
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -45,6 +45,6 @@ def test_c_host_renders_what_the_oracle_renders(tmp_path, C, E, La, Lir, log2_bl
         want = orc.render_event(clips[e], irs[:, [e], :].astype(np.float64), float(snr[e]), ref_db=ref_db, sr=sr)["spatial"]
         got = spatial[e] * scale[e]
         for c in range(C):
-            assert rel_rms(got[c], want[c]) < TOL, (e, c)
+            assert_parity(got[c], want[c], TOL, what=(e, c))
         want_scene += want
-    assert rel_rms(scene, want_scene) < TOL
+    assert_parity(scene, want_scene, TOL)

@@ -7,17 +7,15 @@ import numpy as np
 import pytest
 
 from oracle import synth_oracle as orc
-from tests.conftest import rel_rms
+from tests.conftest import assert_parity, rel_rms
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
 def assert_close(got, ref, tol=TOL):
-    ref = np.asarray(ref, dtype=np.float64)
-    assert got.shape == ref.shape
-    assert rel_rms(got, ref) <= tol
-    assert np.max(np.abs(got - ref)) <= 10 * tol * np.max(np.abs(ref))
+    """The contract's bound, both halves: relative RMS <= tol and max|err| <= tol * max|ref|."""
+    assert_parity(got, ref, tol)
 
 
 @pytest.fixture(scope="module")
@@ -181,7 +179,7 @@ def test_full_size_properties(gpu, planning, name):
     gains = gpu.mem.download(res.emitter_gain)
     for e, c in ((3, 5), (40, 31), (63, 0)):
         ref = fftconvolve(sc.clips[e].astype(np.float64), sc.irs[c, e].astype(np.float64))[: sc.specs[e].n_samples]
-        assert rel_rms(res.raw_spatial(e)[c], ref * gains[e]) < TOL
+        assert_close(res.raw_spatial(e)[c], ref * gains[e])
         e_ref = orc.emitter_gains(sc.irs[:, [e], :].astype(np.float64))[0]
         assert gains[e] == pytest.approx(e_ref, rel=1e-5)
     # mixdown of the whole scene: every output sample is the float32 sum the kernel's own inputs imply (all 64 events)
@@ -207,7 +205,7 @@ def test_full_size_properties(gpu, planning, name):
     ref6 = orc.mix_scene(spat, list(zip(sc.starts[:n6], sc.ends[:n6])), sc.duration, sc.sr, keep_padded=False)["scene"]
     assert scene6.shape == ref6.shape == (sc.n_capsules, 2880000)
     for row in range(sc.n_capsules):
-        assert rel_rms(scene6[row], ref6[row]) < TOL, row
+        assert_parity(scene6[row], ref6[row], TOL, what=row)
 
 
 @pytest.mark.parametrize("seed", range(12))

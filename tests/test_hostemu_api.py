@@ -9,7 +9,7 @@ import pytest
 from audiblelight_amd import _hip, augmentation as aug, core, engine, synthesize as syn
 from oracle import synth_oracle as orc
 from tests import hostemu
-from tests.conftest import pcm16, rel_rms
+from tests.conftest import assert_parity, pcm16, rel_rms
 
 TOL = 1e-4
 
@@ -47,16 +47,16 @@ def test_scene_generate_matches_reference(golden):
     scene = build_g8_scene(golden)
     out = scene.generate()
     assert out["mic000"].dtype == np.float32 and out["mic000"].shape == golden["g8_scene"].shape
-    assert rel_rms(out["mic000"], golden["g8_scene"]) < TOL
+    assert_parity(out["mic000"], golden["g8_scene"], TOL)
     for i, ev in enumerate(scene.events.values()):
         assert ev.spatial_audio.is_resident("mic000")           # still in "HBM" until somebody reads it
         got = ev.spatial_audio["mic000"]
         assert isinstance(got, np.ndarray) and not ev.spatial_audio.is_resident("mic000")
-        assert rel_rms(got, golden[f"g8_spatial{i}"]) < TOL
-        assert rel_rms(ev._spatial_audio_padded["mic000"], golden[f"g8_padded{i}"]) < TOL
+        assert_parity(got, golden[f"g8_spatial{i}"], TOL)
+        assert_parity(ev._spatial_audio_padded["mic000"], golden[f"g8_padded{i}"], TOL)
     ev4 = scene.events["ev4"]
-    assert rel_rms(ev4._spatial_audio_dry["mic000"], golden["g8_dry4"]) < TOL
-    assert rel_rms(ev4._spatial_audio_dry_padded["mic000"], golden["g8_dry_padded4"]) < TOL
+    assert_parity(ev4._spatial_audio_dry["mic000"], golden["g8_dry4"], TOL)
+    assert_parity(ev4._spatial_audio_dry_padded["mic000"], golden["g8_dry_padded4"], TOL)
 
 
 def test_render_cache_and_host_arrays(golden):
@@ -97,7 +97,7 @@ def test_render_event_audio_and_errors(golden):
     a, h = golden["g1_audio"], golden["g1_irs"]
     ev = core.Event("g1", a, 8000, snr=10.0)
     syn.render_event_audio(ev, h, "mic000", ref_db=-65)
-    assert rel_rms(ev.spatial_audio["mic000"], golden["g1_spatial"]) < TOL
+    assert_parity(ev.spatial_audio["mic000"], golden["g1_spatial"], TOL)
     with pytest.raises(ValueError, match="Moving Event has only one emitter!"):
         syn.render_event_audio(core.Event("m", a, 8000, n_emitters=1, is_moving=True), h, "mic000")
     with pytest.raises(ValueError, match="Expected a moving event!"):
@@ -235,7 +235,7 @@ def test_scene_with_device_ambience(golden):
     scene = build_g8_scene(golden, with_ambience=False)
     scene.add_ambience(amb.Ambience(channels=4, duration=2.0, alias="a0", noise="white", ref_db=-65, sample_rate=8000))
     out = scene.generate()["mic000"]
-    assert rel_rms(out, golden["g8_scene"]) < TOL
+    assert_parity(out, golden["g8_scene"], TOL)
     with pytest.raises(ValueError, match="does not match expected shape"):
         bad = build_g8_scene(golden, with_ambience=False)
         bad.add_ambience(amb.Ambience(channels=4, duration=1.0, alias="a0", noise="white", sample_rate=8000))
@@ -257,9 +257,10 @@ def test_two_microphones_with_different_capsule_counts(golden):
         ev_a, ev_b = scene.events["a"], scene.events["b"]
         want_a = orc.render_event(ev_a.load_audio(), h[:, :1, :], 10.0, ref_db=-60, sr=sr)["spatial"]
         want_b = orc.render_event(ev_b.load_audio(), h[:, 1:3, :], 20.0, ref_db=-60, is_moving=True, duration=ev_b.duration, sr=sr)["spatial"]
-        assert rel_rms(ev_a.spatial_audio[mic], want_a) < TOL and rel_rms(ev_b.spatial_audio[mic], want_b) < TOL
+        assert_parity(ev_a.spatial_audio[mic], want_a, TOL)
+        assert_parity(ev_b.spatial_audio[mic], want_b, TOL)
         ref = orc.mix_scene([want_a, want_b], [(0.1, ev_a.scene_end), (0.5, ev_b.scene_end)], 1.0, sr, keep_padded=False)["scene"]
-        assert rel_rms(out[mic], ref) < TOL
+        assert_parity(out[mic], ref, TOL)
 
 
 def test_scene_json_round_trip(golden, tmp_path):
@@ -296,10 +297,10 @@ def test_reference_format_scene_json_renders_like_the_reference(tmp_path):
     assert [type(a).__name__ for a in scene.events["event001"].augmentations] == ["Gain", "Invert"]
     out = scene.generate(output_dir=str(tmp_path), audio_subtype="FLOAT")
     for mic in irs:
-        assert rel_rms(out[mic], z[f"scene_{mic}"]) < TOL
+        assert_parity(out[mic], z[f"scene_{mic}"], TOL)
         for alias, ev in scene.events.items():
-            assert rel_rms(ev.spatial_audio[mic], z[f"spatial_{mic}_{alias}"]) < TOL
-    assert rel_rms(scene.events["event003"]._spatial_audio_dry["mic000"], z["dry_mic000_event003"]) < TOL
+            assert_parity(ev.spatial_audio[mic], z[f"spatial_{mic}_{alias}"], TOL)
+    assert_parity(scene.events["event003"]._spatial_audio_dry["mic000"], z["dry_mic000_event003"], TOL)
     # what we write back has the reference's layout: same keys at every level the reference's from_dict reads
     ours = json.load(open(tmp_path / "metadata_out.json"))
     assert set(ours) == set(meta)
@@ -359,13 +360,13 @@ def test_stft_helpers_match_reference():
     y = syn.perform_time_variant_convolution(z["g10_stft_audio"], z["g10_stft_irs"], z["g10_w"])
     close(y, z["g10_tv"])
     x = syn.istft_overlap_synthesis(z["g10_tv"], 512, 256, 128)
-    assert rel_rms(x, z["g10_istft"]) < TOL
-    assert rel_rms(syn.istft_overlap_synthesis(z["g10_stft_b"][:, :, None], 256, 128, 64), z["g10_istft_b"]) < TOL
+    assert_parity(x, z["g10_istft"], TOL)
+    assert_parity(syn.istft_overlap_synthesis(z["g10_stft_b"][:, :, None], 256, 128, 64), z["g10_istft_b"], TOL)
     # the chain of the three equals time_variant_convolution's envelope-form render of the same event
     ev = core.Event("mv", a, 8000, snr=10.0, n_emitters=3)
     tv = syn.time_variant_convolution(h.astype(np.float64), ev)
     chain = syn.istft_overlap_synthesis(syn.perform_time_variant_convolution(s_a, s_h, z["g10_w"])).T
-    assert rel_rms(tv[:, : chain.shape[1]], chain[:, : tv.shape[1]]) < TOL
+    assert_parity(tv[:, : chain.shape[1]], chain[:, : tv.shape[1]], TOL)
     with pytest.raises(Exception, match="fft_size must factor"):
         syn.stft(a, 2 * 11 * 13, 256, 128)
 
@@ -395,13 +396,13 @@ def test_fx_chain_stays_on_device_and_scalars_fold():
     for i, ev in enumerate(scene.events.values()):
         want = orc.render_event(want_clips[i], irs[:, [i], :].astype(np.float64), ev.snr, sr=sr)["spatial"]
         spatials.append(want)
-        assert rel_rms(ev.spatial_audio["mic000"], want) < TOL
+        assert_parity(ev.spatial_audio["mic000"], want, TOL)
         assert ev.audio is None                         # nobody asked for the host clip: it never came back
     assert getattr(scene.events["e0"], "_last_chain", None) is None          # folded: no FX kernel, no device clip
     chain_clip = scene.events["e2"]._last_chain
     assert chain_clip.uploads == 1 and chain_clip.downloads == 0            # three FX + normalisation, zero D2H
     ref = orc.mix_scene(spatials, [(e.scene_start, e.scene_end) for e in scene.events.values()], 1.0, sr, keep_padded=False)["scene"]
-    assert rel_rms(scene.audio["mic000"], ref) < TOL
+    assert_parity(scene.audio["mic000"], ref, TOL)
     # the host API still gives the reference's answer, through one upload and one download
     ev = core.Event("h", raws[2], sr, augmentations=chains[2])
     assert rel_rms(ev.load_audio(), want_clips[2]) < 1e-6
@@ -439,7 +440,7 @@ def test_ir_ingest_ragged_packing_and_resampling():
     res = r.prepare(pl, clips, dev, strides).run()
     for n in range(N):
         ref = orc.render_event(clips[n], want[:, [n], :], 10.0, sr=8000)["spatial"]
-        assert rel_rms(res.spatial_audio(n), ref) < TOL
+        assert_parity(res.spatial_audio(n), ref, TOL)
     # resampling 44.1 kHz -> 48 kHz (160/147) and 48 -> 16 kHz (1/3)
     h = (rng.standard_normal((2, 3, 900)) * np.exp(-np.arange(900) / 150.0)).astype(np.float32)
     for a, b in ((44100, 48000), (48000, 16000)):

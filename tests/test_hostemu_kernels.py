@@ -11,7 +11,7 @@ import pytest
 from audiblelight_amd import _hip, engine, plan as planning
 from oracle import synth_oracle as orc
 from tests import hostemu
-from tests.conftest import rel_rms
+from tests.conftest import assert_parity, rel_rms
 
 TOL = 1e-4  # BASELINE.json north_star: outputs within 1e-4 relative RMS of the float64 reference
 
@@ -38,8 +38,8 @@ def test_emu_static_event_matches_reference(emu, golden, log2_block):
     g = emu.mem.download(res.emitter_gain)[:1]
     np.testing.assert_allclose(g, orc.emitter_gains(h.astype(np.float64)), rtol=1e-5)
     raw_ref = golden["g1_full_conv"][:, : len(a)] * orc.emitter_gains(h.astype(np.float64))[0]
-    assert rel_rms(res.raw_spatial(0), raw_ref) < TOL
-    assert rel_rms(res.spatial_audio(0), golden["g1_spatial"]) < TOL
+    assert_parity(res.raw_spatial(0), raw_ref, TOL)
+    assert_parity(res.spatial_audio(0), golden["g1_spatial"], TOL)
     res.check_finite()
 
 
@@ -50,7 +50,7 @@ def test_emu_narrow_transforms_at_large_blocks(emu, golden, monkeypatch, log2_bl
     a, h = golden["g1b_audio"], golden["g1b_irs"]
     pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=0.5, ref_db=-50)],
                              n_capsules=3, ir_len=h.shape[2], sample_rate=8000, log2_block=log2_block)
-    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1b_spatial"]) < TOL
+    assert_parity(emu.render(pl, [a], h).spatial_audio(0), golden["g1b_spatial"], TOL)
 
 
 @pytest.mark.parametrize("log2_block", [10, 13])
@@ -60,7 +60,7 @@ def test_emu_runs_of_blocks_per_workgroup(emu, golden, monkeypatch, log2_block):
     a, h = golden["g1_audio"], golden["g1_irs"]
     pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=10.0)], 4, h.shape[2], 8000,
                              log2_block=log2_block)
-    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g1_spatial"]) < TOL
+    assert_parity(emu.render(pl, [a], h).spatial_audio(0), golden["g1_spatial"], TOL)
 
 
 def test_emu_moving_event_wide_transforms(emu, golden):
@@ -68,7 +68,7 @@ def test_emu_moving_event_wide_transforms(emu, golden):
     a, h = golden["g3b_audio"], golden["g3b_irs"]
     spec = planning.EventSpec(n_samples=len(a), n_emitters=5, snr=12.0, is_moving=True, duration=len(a) / 8000)
     pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=13)
-    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"]) < TOL
+    assert_parity(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"], TOL)
 
 
 @pytest.mark.parametrize("log2_block", [13, 14])
@@ -77,7 +77,7 @@ def test_emu_large_blocks(emu, golden, log2_block):
     pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=0.5, ref_db=-50)],
                              n_capsules=3, ir_len=h.shape[2], sample_rate=8000, log2_block=log2_block)
     res = emu.render(pl, [a], h)
-    assert rel_rms(res.spatial_audio(0), golden["g1b_spatial"]) < TOL
+    assert_parity(res.spatial_audio(0), golden["g1b_spatial"], TOL)
 
 
 def test_emu_zero_emitter_event(emu, golden):
@@ -95,8 +95,8 @@ def test_emu_moving_event(emu, golden, tag, n_ir):
     pl = planning.plan_batch([spec], n_capsules=4, ir_len=h.shape[2], sample_rate=8000, log2_block=10)
     res = emu.render(pl, [a], h)
     raw_ref = orc.fit_length(golden[f"{tag}_raw"], len(a))
-    assert rel_rms(res.raw_spatial(0), raw_ref) < TOL
-    assert rel_rms(res.spatial_audio(0), golden[f"{tag}_spatial"]) < TOL
+    assert_parity(res.raw_spatial(0), raw_ref, TOL)
+    assert_parity(res.spatial_audio(0), golden[f"{tag}_spatial"], TOL)
 
 
 def test_emu_moving_event_sliding_window_kernel(emu, golden):
@@ -105,7 +105,7 @@ def test_emu_moving_event_sliding_window_kernel(emu, golden):
     spec = planning.EventSpec(n_samples=len(a), n_emitters=5, snr=12.0, is_moving=True, duration=len(a) / 8000)
     pl = planning.plan_batch([spec], 4, h.shape[2], 8000, log2_block=12)
     assert pl.events["reserved"][0] == 1 and int(pl.streams["n_j"].max()) <= 4
-    assert rel_rms(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"]) < TOL
+    assert_parity(emu.render(pl, [a], h).spatial_audio(0), golden["g3b_spatial"], TOL)
     # and next to a static event + a long-stream moving event in the same batch (both kernels run)
     a2, h2 = golden["g1_audio"], golden["g1_irs"]
     a3, h3 = golden["g3a_audio"], golden["g3a_irs"][:, :, :1200]
@@ -114,9 +114,9 @@ def test_emu_moving_event_sliding_window_kernel(emu, golden):
     irs = np.concatenate([h2[:, :, :1200], h], axis=1)
     pl2 = planning.plan_batch(specs, 4, 1200, 8000, log2_block=12)
     res = emu.render(pl2, [a2, a], irs)
-    assert rel_rms(res.spatial_audio(1), golden["g3b_spatial"]) < TOL
+    assert_parity(res.spatial_audio(1), golden["g3b_spatial"], TOL)
     want = orc.render_event(a2, irs[:, :1, :].astype(np.float64), 10.0, sr=8000)["spatial"]
-    assert rel_rms(res.spatial_audio(0), want) < TOL
+    assert_parity(res.spatial_audio(0), want, TOL)
 
 
 def test_emu_full_scene_with_ambience(emu, golden):
@@ -133,7 +133,7 @@ def test_emu_full_scene_with_ambience(emu, golden):
     pl = planning.plan_batch(specs, n_capsules=C, ir_len=mic_ir.shape[2], sample_rate=sr, log2_block=10)
     res = emu.render(pl, clips, mic_ir)
     for i in range(len(specs)):
-        assert rel_rms(res.spatial_audio(i), golden[f"g8_spatial{i}"]) < TOL
+        assert_parity(res.spatial_audio(i), golden[f"g8_spatial{i}"], TOL)
     # chunked execution over a reused workspace gives bit-identical results
     for chunk in (1, 2):
         res_c = emu.render(pl, clips, mic_ir, chunk_events=chunk)
@@ -152,7 +152,7 @@ def test_emu_full_scene_with_ambience(emu, golden):
     mult = np.float32(orc.db_gain(-65, stats[0, 0] / amb.size))
     scene = emu.mem.download(emu.mixdown(mix, res, ambience=[(amb_dev, emu.mem.upload(np.full(mix.n_capsules, mult, np.float32)))]))
     scene = scene[: C * mix.n_samples].reshape(C, mix.n_samples)
-    assert rel_rms(scene, golden["g8_scene"]) < TOL
+    assert_parity(scene, golden["g8_scene"], TOL)
     # without ambience: plain overwrite path
     scene2 = emu.mem.download(emu.mixdown(mix, res))[: C * mix.n_samples].reshape(C, mix.n_samples)
     want = golden["g8_scene"].astype(np.float64) - mult * amb.astype(np.float64)

@@ -97,6 +97,11 @@ def default_rng_mode() -> str:
     return mode
 
 
+def _clone(buf):
+    """A copy of a device buffer in the memory provider's own type (torch tensor or, under host emulation, ndarray)."""
+    return buf.clone() if hasattr(buf, "clone") else np.array(buf)
+
+
 def _seed64(seed) -> int:
     """Key of the device generator.  ``seed=None`` means fresh entropy, as ``np.random.default_rng(None)`` does for the host draws."""
     if seed is None:
@@ -235,10 +240,12 @@ class Ambience:
         """(channels * total) float32 in HBM, not yet peak-normalised."""
         if self.beta is not None:
             if self.beta == "gaussian":
-                if self.rng == "device":   # ambience.py:160-165 draws from the GLOBAL numpy RNG; here the seed kwarg rules
+                if self.rng == "device":   # ambience.py:160-165 draws from the GLOBAL numpy RNG: every Ambience gets fresh noise.
+                    # Mirrored here: no seed kwarg = fresh entropy per draw (a fixed default would put the SAME noise into every
+                    # scene of a dataset); only an explicit seed= makes the realisation reproducible.
                     dev = r.mem.empty(self.channels * total)
                     r.lib.call("al_normal_fill", r.mem.ptr(dev), self.channels * total,
-                               ct.c_uint64(_seed64(self.noise_kwargs.get("seed", config.SEED))), 3, 1.0, r.mem.stream())
+                               ct.c_uint64(_seed64(self.noise_kwargs.get("seed", None))), 3, 1.0, r.mem.stream())
                     return dev
                 return r.mem.upload(np.random.normal(0, 1, (self.channels, total)).astype(np.float32).reshape(-1))
             return powerlaw_noise_device(r, self.beta, self.channels, total, rng=self.rng, **self.noise_kwargs)
@@ -259,7 +266,10 @@ class Ambience:
             return self._device
         r = renderer or _renderer()
         total = round(self.duration * self.sample_rate)
-        dev = self._generate_device(r, total)
+        # the realisation a scene has already MIXED (noise_and_scales_device) is the one this Ambience hands out afterwards,
+        # as the reference caches the array it mixed (ambience.py:142-148): derived from that buffer, not drawn again
+        mixed = None if ignore_cache else getattr(self, "_scaled", None)
+        dev = _clone(mixed[0]) if mixed is not None else self._generate_device(r, total)
         if normalize and self.rng == "device" and self.channels <= 1024:
             # per-channel 1 / (peak + tiny) from device statistics, applied on the device: no host round trip
             scales = r.mem.empty(self.channels)
@@ -269,7 +279,8 @@ class Ambience:
         elif normalize:
             peak_normalize_rows_device(r, dev, self.channels, total)
         self._device, self.device_shape = dev, (self.channels, total)
-        self._scaled = None
+        if mixed is None:
+            self._scaled = None
         return dev
 
     def noise_and_scales_device(self, renderer, shape):
@@ -285,10 +296,11 @@ class Ambience:
             raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {(self.channels, total)}.")
         if getattr(self, "_scaled", None) is not None:
             return self._scaled
-        dev = self._generate_device(r, total)
+        cached = self._device if tuple(getattr(self, "device_shape", ()) or ()) == (self.channels, total) else None
+        dev = cached if cached is not None else self._generate_device(r, total)   # a buffer load_ambience_device made is the one mixed
         scales = r.mem.empty(self.channels)
         r.lib.call("al_ambience_scales", r.mem.ptr(r.row_stats(dev, self.channels, total)), self.channels, total,
-                   float(self.ref_db), 1, r.mem.ptr(scales), r.mem.stream())
+                   float(self.ref_db), 1, r.mem.ptr(scales), r.mem.stream())   # 1 / (peak + tiny) of an already normalised row is 1
         self._scaled = (dev, scales)
         return self._scaled
 
@@ -297,7 +309,8 @@ class Ambience:
         if self.is_audio_loaded and not ignore_cache:
             return self.audio
         r = _renderer()
-        dev = self.load_ambience_device(r, ignore_cache=True, normalize=bool(normalize))
+        self._device = None
+        dev = self.load_ambience_device(r, ignore_cache=bool(ignore_cache), normalize=bool(normalize))
         c, n = self.device_shape
         self.audio = r.mem.download(dev)[: c * n].reshape(c, n).astype(np.float64)
         return self.audio
@@ -306,9 +319,8 @@ class Ambience:
         d = dict(alias=self.alias, beta=self.beta, filepath=str(self.filepath) if self.filepath is not None else None,
                  channels=self.channels, sample_rate=self.sample_rate, duration=self.duration, ref_db=self.ref_db,
                  noise_kwargs=self.noise_kwargs)
-        if self.rng == "device" and default_rng_mode() != "device":
-            d["rng"] = "device"     # beyond the reference's layout, only when it differs from the default: the realisation depends on it
-        return d
+        d["rng"] = self.rng         # beyond the reference's layout (from_dict tolerates its absence): the realisation depends on it,
+        return d                    # and an explicit rng="host" must survive AL_AMBIENCE_RNG=device at load time
 
     @classmethod
     def from_dict(cls, input_dict: dict[str, Any]):

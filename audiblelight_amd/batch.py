@@ -38,7 +38,8 @@ class SceneJob:
     duration: float
     sample_rate: int
     name: str = "scene"
-    ambience: Sequence = ()         # [(device noise buffer, device scalar)] prepared by the caller, optional
+    ambience: Sequence = ()         # [(device noise (C * T floats), device float32[C] per-capsule multipliers)] prepared by the
+                                    # caller, optional (a 1-element multiplier buffer is broadcast over the capsules)
 
 
 @dataclass

@@ -445,6 +445,9 @@ __global__ __launch_bounds__(512, 2) void k_spectral_mac_static_lds(al_batch b) 
 // The DMA is inline asm (hipcc would drain every outstanding one with vmcnt(0) before the first LDS read it knows to depend
 // on it); the waits are therefore counted by hand.  Every wave issues the same number of pieces (the last piece is fetched
 // again where PT * 4 is not a multiple of 8) and every half issues exactly its own number of stores per capsule.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "k_spectral_mac_static_glds counts stores in vmcnt and uses global_load_lds_dwordx4: gfx950 only (a target with a separate store counter would read stale LDS)"
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 // 64 lanes x 16 B from (uniform base in SGPRs) + (lane offset in ONE VGPR shared by every piece) into LDS at lds_dst + lane * 16:
 // all the address arithmetic of a piece is scalar
@@ -553,6 +556,7 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
 #endif
   };
   static_assert(KT <= 12, "the counted waits enumerate at most 12 stores per capsule");
+  static_assert(PER_WAVE + 24 <= 63, "vmcnt is a 6-bit counter: the pieces of a unit plus two capsules' stores must fit it");
   issue(0);
   issue(1);
   int n = 0;

@@ -526,6 +526,19 @@ class Renderer:
         host_tabs = (mix.tile_ptr, mix.tile_events, mix.slot_src, mix.slot_len, mix.slot_start, mix.slot_count, mix.slot_rows,
                      mix.slot_event)
         tabs = mem.upload_tables(host_tabs) if hasattr(mem, "upload_tables") else [mem.upload(x) for x in host_tabs]
+        # every ambience comes with ONE multiplier per capsule (k_mixdown reads ambience_scale[c], al_axpy_rows a[row]):
+        # a shorter buffer would be read out of bounds, so a single scalar is broadcast and anything else is refused
+        checked = []
+        for noise, scales in ambience:
+            have = int(scales.numel()) if hasattr(scales, "numel") else int(np.size(scales))
+            if have == 1 and mix.n_capsules > 1:
+                wide = mem.empty(mix.n_capsules)
+                wide[: mix.n_capsules] = scales[0]
+                scales = wide
+            elif have < mix.n_capsules:
+                raise ValueError(f"ambience multipliers: {have} values for {mix.n_capsules} capsules (one per capsule, or one scalar)")
+            checked.append((noise, scales))
+        ambience = checked
         # exactly one ambience and a fresh scene buffer (the normal case): added inside the mixdown kernel
         fused = list(ambience) if (len(ambience) == 1 and scene is None) else []
         ambience = [] if fused else list(ambience)

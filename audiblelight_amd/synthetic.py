@@ -29,6 +29,8 @@ class SyntheticScene:
     irs: np.ndarray             # (C, sum N, Lir) float32
     specs: List[EventSpec]
     starts: List[float]
+    irs_dev: object = None        # bench only: the IR tensor drawn ON THE DEVICE (flat float32, same law), then `irs` is None
+    ir_shape: tuple = ()          # (C, sum N, Lir) whichever side holds the tensor
     ambience_beta: object = None  # noise colour of the scene ambience (cfg5: "white"), None = no ambience
     gain_db: object = None        # cfg5: per-event Gain(gain_db) of the [Gain, Invert] chain; `clips` are then RAW clips
 
@@ -58,25 +60,41 @@ class SyntheticScene:
     def algorithmic_bytes(self) -> int:
         """Inputs read once + scene.audio written once (SURVEY 8d "scene-only contract")."""
         audio = sum(len(c) for c in self.clips) * 4
-        return audio + self.irs.size * 4 + self.n_capsules * round(self.duration * self.sr) * 4
+        n_ir = int(np.prod(self.ir_shape)) if self.irs is None else self.irs.size
+        return audio + n_ir * 4 + self.n_capsules * round(self.duration * self.sr) * 4
 
 
-def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, **override) -> SyntheticScene:
-    """White-noise clips + exponentially decaying random IRs with a unit direct tap."""
+def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, torch_device=None, **override) -> SyntheticScene:
+    """White-noise clips + exponentially decaying random IRs with a unit direct tap.
+
+    ``torch_device``: draw the IR tensor on that device instead (torch.randn, same law: N(0,1) x exp(-t / tau) plus a unit tap
+    at a random early sample per row); for timing legs whose 6.3 GB of host draws would take longer than the measurement.
+    The parity tests always use the host draws."""
     cfg = dict(CONFIGS[name])
     cfg.update(override)
     sr, C, E, N = cfg["sr"], cfg["C"], cfg["E"], cfg["N"]
     Lir, La, T = int(cfg["Lir"] * scale), int(cfg["La"] * scale), cfg["T"] * scale
     rng = np.random.default_rng(1234 + scene_index)
     decay = np.exp(-np.arange(Lir, dtype=np.float32) / np.float32(Lir / 6.9))
-    irs = np.empty((C, E * N, Lir), dtype=np.float32)
+    irs = np.empty((C, E * N, Lir), dtype=np.float32) if torch_device is None else None
+    irs_dev = None
+    if torch_device is not None:
+        import torch
+
+        gen = torch.Generator(device=torch_device)
+        gen.manual_seed(1234 + scene_index)
+        irs_dev = torch.randn((C * E * N, Lir), generator=gen, device=torch_device, dtype=torch.float32)
+        irs_dev *= torch.from_numpy(decay).to(torch_device)[None, :]
+        taps = torch.randint(48, min(960, Lir), (C * E * N,), generator=gen, device=torch_device)
+        irs_dev[torch.arange(C * E * N, device=torch_device), taps] += 1.0
+        irs_dev = irs_dev.reshape(-1)
     clips, specs, starts, gains_db = [], [], [], []
     for e in range(E):
         a = rng.standard_normal(La, dtype=np.float32)
         if not cfg.get("fx"):   # finished clip: peak-normalised as Event.load_audio leaves it (event.py:535-536)
             a = a / np.max(np.abs(a) + np.finfo(np.float32).tiny)
         clips.append(a.astype(np.float32))
-        for n in range(N):
+        for n in range(N if irs is not None else 0):
             h = rng.standard_normal((C, Lir), dtype=np.float32) * decay
             h[np.arange(C), rng.integers(48, min(960, Lir), size=C)] += 1.0
             irs[:, e * N + n, :] = h
@@ -86,4 +104,5 @@ def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, **o
                                is_moving=N > 1, duration=La / sr, ref_db=-65.0))
         starts.append(float(rng.uniform(0, max(T - La / sr, 0.0))))
     return SyntheticScene(name=name, sr=sr, duration=T, n_capsules=C, ir_len=Lir, clips=clips, irs=irs, specs=specs,
-                          starts=starts, ambience_beta=cfg.get("ambience"), gain_db=gains_db if cfg.get("fx") else None)
+                          starts=starts, irs_dev=irs_dev, ir_shape=(C, E * N, Lir), ambience_beta=cfg.get("ambience"),
+                          gain_db=gains_db if cfg.get("fx") else None)

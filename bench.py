@@ -319,7 +319,12 @@ def resident_scene(r, scene, args):
     from audiblelight_amd import plan as planning
 
     pl = planning.plan_batch(scene.specs, scene.n_capsules, scene.ir_len, scene.sr, log2_block=args.log2_block)
-    batch = r.prepare(pl, scene.sources(), scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
+    if scene.irs is None:   # IR tensor drawn on the device (other_configs leg): handed over as a device buffer + strides
+        c, n, l = scene.ir_shape
+        assert l % 4 == 0
+        batch = r.prepare(pl, scene.sources(), scene.irs_dev, ir_strides=(n * l, l), chunk_events=args.chunk_events, lanes=args.lanes)
+    else:
+        batch = r.prepare(pl, scene.sources(), scene.irs, chunk_events=args.chunk_events, lanes=args.lanes)
     n_ev = len(scene.clips)
     mix_plan = planning.plan_mixdown(scene.starts, scene.ends, [len(c) for c in scene.clips], [scene.n_capsules] * n_ev,
                                      pl.events["out_off"], list(range(n_ev)), scene.duration, scene.sr, scene.n_capsules)
@@ -368,6 +373,9 @@ def main():
     ap.add_argument("--dropin", type=int, default=None, metavar="N",
                     help="also time N calls of Scene.generate() (the drop-in API: host numpy clips + IRs in, scene.audio "
                          "out, synchronous; default 8 on one GPU for static configs, 0 otherwise)")
+    ap.add_argument("--other-configs", type=int, default=1, metavar="0|1",
+                    help="on the default single-GPU cfg2 run also time a few steps of cfg3, cfg4 and cfg5 (compact leg "
+                         "`other_configs` of the JSON line; 0 = skip)")
     ap.add_argument("--graph", action="store_true",
                     help="replay the scene as one HIP graph (engine.CapturedScene) instead of seven launches")
     ap.add_argument("--gather", dest="gather", action="store_true", default=None,
@@ -553,6 +561,9 @@ def run_scene_per_rank_mode(ctx):
                       {"scenes_per_step_per_gpu": 1})
     out["timing"]["ms_per_step_by_rank_last_repeat"] = [round(x, 4) for x in by_rank]
     out["timing"]["ms_per_step_with_stage_events"] = instrumented / args.steps * 1e3
+    # what one step IS, rank for rank: the same C-ABI calls in the same order whether N = 1 or N > 1 (every rank runs this very
+    # function on its own scene), so the N = 1 line of a scaling sweep must equal the single-GPU bench line
+    out["config"]["step_calls"] = stages if not chunked else ["al_render_batch (chunked)", "al_mixdown"]
     out["roofline"] = {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                        "frac": achieved / HBM_PEAK_GBS,
                        # the same algorithmic bytes over the WHOLE step (all kernels of the scene), per GPU
@@ -564,6 +575,8 @@ def run_scene_per_rank_mode(ctx):
                        "scene_traffic": sum(v for v in (pmc or {}).values() if isinstance(v, (int, float))) or None,
                        "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                        "hbm_bytes_per_launch_pmc": pmc}
+    if args.other_configs and world == 1 and not emulate and args.config == "cfg2" and args.scale == 1.0:
+        out["other_configs"] = other_configs_leg(ctx, r)
     if args.end_to_end > 0:
         out["end_to_end"] = end_to_end_leg(r, scene, args.end_to_end)
     if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
@@ -577,6 +590,67 @@ def run_scene_per_rank_mode(ctx):
             out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))
         if ctx["all_cores"] is not None:
             out["cpu_baseline_all_cores"] = ctx["all_cores"]
+    return out
+
+
+def other_configs_leg(ctx, r):
+    """BASELINE configs[2..4] on this GPU, a few steps each, so the driver's own run times them too (their full parity tests
+    are tests/test_gpu_full_size.py).  Same step as the headline: every stage of the scene + the mixdown, inputs resident; the
+    6.3 GB IR tensors of cfg3 / cfg5 are drawn on the device (torch.randn, same law) instead of on one host core."""
+    import argparse as ap
+
+    from audiblelight_amd import synthetic
+
+    torch, args = ctx["torch"], ctx["args"]
+    out = {}
+    for name, steps in (("cfg3", 10), ("cfg4", 40), ("cfg5", 8)):
+        t_in = time.perf_counter()
+        scene = synthetic.make_scene(name, scene_index=0, torch_device=f"cuda:{torch.cuda.current_device()}")
+        sub = ap.Namespace(log2_block=None, chunk_events=0, lanes=1)
+        batch, mix, mix_plan, pl = resident_scene(r, scene, sub)
+        stages = list(batch.stage_names()) + ["al_mixdown"]
+
+        def step(events=None):
+            for i, st in enumerate(stages):
+                if events is not None:
+                    events[i][0].record()
+                if st == "al_mixdown":
+                    mix.run()
+                else:
+                    batch.run_stage(st)
+                if events is not None:
+                    events[i][1].record()
+
+        for _ in range(4):      # the first passes over a freshly allocated multi-GB workspace run at a third of the speed
+            step()
+        reps = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _k in range(steps):
+                step()
+            torch.cuda.synchronize()
+            reps.append((time.perf_counter() - t0) / steps)
+        ev = [[(ctx["new_event"](), ctx["new_event"]()) for _ in stages] for _ in range(steps)]
+        for k in range(steps):
+            step(ev[k])
+        torch.cuda.synchronize()
+        batch.result().check_finite()
+        kernel_ms = {st: float(np.mean([ev[k][i][0].elapsed_time(ev[k][i][1]) for k in range(steps)])) for i, st in enumerate(stages)}
+        dominant = max(kernel_ms, key=kernel_ms.get)
+        ms = float(np.median(reps)) * 1e3
+        algo = scene.algorithmic_bytes()
+        pmc, _note = load_pmc_traffic(name, pl.log2_block)
+        out[name] = {"workload": scene.describe(), "ms_per_step": ms, "value": scene.duration / (ms * 1e-3), "steps": steps,
+                     "ms_per_step_each_repeat": [round(x * 1e3, 4) for x in reps], "dominant": dominant,
+                     "frac": algo / (kernel_ms[dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS, "path_frac": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                     "algorithmic_bytes": algo, "traffic": sum(v for v in (pmc or {}).values() if isinstance(v, (int, float))) or None,
+                     "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
+                     "inputs": "clips drawn on the host, IR tensor on the device (same law)",
+                     "setup_s": None}
+        del batch, mix, scene, ev
+        torch.cuda.empty_cache()
+        out[name]["setup_s"] = round(time.perf_counter() - t_in - 4 * steps * ms * 1e-3, 1)
     return out
 
 

@@ -3,7 +3,7 @@
 #   prescribes), summarised into profiles/pmc_traffic.json under one key per config; then the bench lines, which read it.
 #   gpurun -- 'bash profiles/tools/collect_profiles.sh r03a'          (optionally: ... r03a "cfg2 cfg4")
 cd /tmp && export TMPDIR=/tmp; R=$GRAFT_REPO_ROOT; TAG=${1:-r03}; CONFIGS=${2:-"cfg2 cfg3 cfg4 cfg5"}
-QUIET="--cpu-events 0 --cpu-workers 0 --end-to-end 0 --dropin 0 --repeats 1"
+QUIET="--cpu-events 0 --cpu-workers 0 --end-to-end 0 --dropin 0 --other-configs 0 --repeats 1"
 rm -f $R/gpurun_out/${TAG}_pmc_traffic.json
 for CFG in $CONFIGS; do
   case $CFG in cfg2|cfg4) PS=3; SS=50;; *) PS=2; SS=10;; esac
@@ -22,7 +22,7 @@ done
 cd $R
 cp gpurun_out/${TAG}_pmc_traffic.json profiles/pmc_traffic.json   # so the bench lines below carry roofline.traffic
 python3 bench.py > gpurun_out/${TAG}_bench_cfg2.json 2> gpurun_out/${TAG}_bench_cfg2.err; echo "bench cfg2 rc=$?"
-python3 bench.py --steps 20 --warmup 5 --cpu-events 0 --cpu-workers 0 --end-to-end 0 --dropin 0 > gpurun_out/${TAG}_bench_cfg2_steps20.json 2>/dev/null; echo "bench cfg2 (driver's flags) rc=$?"
+python3 bench.py --steps 20 --warmup 5 --cpu-events 0 --cpu-workers 0 --end-to-end 0 --dropin 0 --other-configs 0 > gpurun_out/${TAG}_bench_cfg2_steps20.json 2>/dev/null; echo "bench cfg2 (driver's flags) rc=$?"
 python3 bench.py --config cfg3 --steps 30 --warmup 3 --cpu-events 1 --cpu-workers 0 > gpurun_out/${TAG}_bench_cfg3.json 2>/dev/null; echo "cfg3 rc=$?"
 python3 bench.py --config cfg5 --steps 30 --warmup 3 --cpu-events 1 --cpu-workers 0 --end-to-end 8 --dropin 0 > gpurun_out/${TAG}_bench_cfg5.json 2>/dev/null; echo "cfg5 rc=$?"
 python3 bench.py --config cfg4 --steps 100 --warmup 3 --cpu-workers 0 > gpurun_out/${TAG}_bench_cfg4.json 2>/dev/null; echo "cfg4 rc=$?"

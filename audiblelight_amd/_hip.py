@@ -23,6 +23,9 @@ FLAG_SPLIT_SPECTRA = 32
 FLAG_STATIC_MAC = 64
 FLAG_ONLY_STATIC = 128
 FLAG_NARROW_FFT = 4
+FLAG_QUAD_SPECTRA = 256
+FLAG_FUSED_MOVING = 512
+FLAG_FUSED_NJ5 = 1024
 # bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
 DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (7 << 12) | (0xff << 16) | (0x7f << 24)   # bit 12: static accumulate, one k-tile per workgroup
 
@@ -95,6 +98,7 @@ SYMBOLS = {
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "al_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
+    "al_moving_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
     "al_mac_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),

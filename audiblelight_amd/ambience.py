@@ -245,7 +245,7 @@ class Ambience:
                     # scene of a dataset); only an explicit seed= makes the realisation reproducible.
                     dev = r.mem.empty(self.channels * total)
                     r.lib.call("al_normal_fill", r.mem.ptr(dev), self.channels * total,
-                               ct.c_uint64(_seed64(self.noise_kwargs.get("seed", None))), 3, 1.0, r.mem.stream())
+                               ct.c_uint64(self._gaussian_seed()), 3, 1.0, r.mem.stream())
                     return dev
                 return r.mem.upload(np.random.normal(0, 1, (self.channels, total)).astype(np.float32).reshape(-1))
             return powerlaw_noise_device(r, self.beta, self.channels, total, rng=self.rng, **self.noise_kwargs)
@@ -259,6 +259,16 @@ class Ambience:
             r.lib.call("al_wrap_copy", r.mem.ptr(one), src.shape[1], r.mem.ptr(dev) + 4 * c * total, total, r.mem.stream())
         r.mem.synchronize()
         return dev
+
+    def _gaussian_seed(self) -> int:
+        """Key of this object's device-drawn "gaussian" noise: the seed= keyword, else entropy drawn ONCE per object (so the
+        object reproduces its own realisation, and its dictionary records it), never a fixed default."""
+        seed = self.noise_kwargs.get("seed", None)
+        if seed is not None:
+            return _seed64(seed)
+        if getattr(self, "_entropy", None) is None:
+            self._entropy = _seed64(None)
+        return self._entropy
 
     def load_ambience_device(self, renderer=None, ignore_cache: bool = False, normalize: bool = True):
         """(channels*samples) float32 device buffer of the ambience; cached."""
@@ -319,8 +329,15 @@ class Ambience:
         d = dict(alias=self.alias, beta=self.beta, filepath=str(self.filepath) if self.filepath is not None else None,
                  channels=self.channels, sample_rate=self.sample_rate, duration=self.duration, ref_db=self.ref_db,
                  noise_kwargs=self.noise_kwargs)
-        d["rng"] = self.rng         # beyond the reference's layout (from_dict tolerates its absence): the realisation depends on it,
-        return d                    # and an explicit rng="host" must survive AL_AMBIENCE_RNG=device at load time
+        # "rng" is beyond the reference's layout (from_dict tolerates its absence), so the plain case -- host draws under the
+        # default environment -- keeps the reference's exact dictionary; every other case records it: a device Ambience
+        # always (the realisation depends on it, whatever AL_AMBIENCE_RNG says when the file is read back), and an explicit
+        # rng="host" made under AL_AMBIENCE_RNG=device
+        if self.rng != "host" or default_rng_mode() != "host":
+            d["rng"] = self.rng
+        if self.rng == "device" and self.beta == "gaussian" and getattr(self, "_entropy", None) is not None:
+            d["noise_kwargs"] = dict(self.noise_kwargs, seed=self._entropy)   # the realisation this object drew, reproducible from its dictionary
+        return d
 
     @classmethod
     def from_dict(cls, input_dict: dict[str, Any]):

@@ -141,5 +141,7 @@ hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream);
 hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream);
+hipError_t launch_moving_fused(const al_batch *b, hipStream_t stream);   // csrc/al_quad.h
+int moving_fused_code(const al_batch *b);
 
 }  // namespace al

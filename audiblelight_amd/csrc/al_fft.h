@@ -407,13 +407,51 @@ __device__ __forceinline__ void fft_regs_to_regs(float2 (&v)[G::E], float2 *s, c
   FftPasses<G, DIR, 0, true>::run(v, s, t, tid);
 }
 
+// ---- where slot q of a spectrum half lives
+// PlainSlots: at q (the layouts of DESIGN.md sections 2 and 5.2).
+// QuadSlots<M>: the "quad" layout of csrc/al_quad.h for the split kernels (M = B/2 slots per half, Q = M/2): every half is
+// stored as two tiles of Q slots, each of which is a plain Q-point complex transform of the (folded, twisted) window -- so a
+// workgroup that owns ONE tile can make its own slice of an IR partition's spectrum from the raw samples:
+//   even half (E[q] = W[2q], q < M):  T0[i] = E[2i]            (slot 0 still packs W[0] and W[B])
+//                                     T1[i] = E[4i + 1], i < Q  (for 4i + 1 > M the VALUE of that bin, i.e. the conjugate
+//                                             of the stored E[2M - 4i - 1]; slots q = 3 mod 4 land there conjugated)
+//   odd half  (U[q] = W[4q + 1]):     T2[i] = U[2i],  T3[i] = U[2i + 1]
+// The accumulate is element-wise on slots, so any consistent permutation (+ conjugation) of X, H and Y is transparent to it.
+struct PlainSlots {
+  static __device__ __forceinline__ void store_even(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }
+  static __device__ __forceinline__ void store_odd(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }
+  static __device__ __forceinline__ float2 load_even(const float2 *half, int q) { return stream_load<2>(half + q); }
+  static __device__ __forceinline__ float2 load_odd(const float2 *half, int q) { return stream_load<2>(half + q); }
+};
+template <int M>
+struct QuadSlots {
+  static constexpr int Q = M / 2;
+  static __device__ __forceinline__ int even_slot(int q, bool &conj) {
+    conj = (q & 3) == 3;
+    return (q & 1) == 0 ? (q >> 1) : (conj ? Q + ((2 * M - q - 1) >> 2) : Q + ((q - 1) >> 2));
+  }
+  static __device__ __forceinline__ int odd_slot(int q) { return (q & 1) ? Q + (q >> 1) : (q >> 1); }
+  static __device__ __forceinline__ void store_even(float2 *half, int q, float2 v) {
+    bool cj;
+    const int d = even_slot(q, cj);
+    half[d] = cj ? make_float2(v.x, -v.y) : v;
+  }
+  static __device__ __forceinline__ void store_odd(float2 *half, int q, float2 v) { half[odd_slot(q)] = v; }
+  static __device__ __forceinline__ float2 load_even(const float2 *half, int q) {
+    bool cj;
+    const float2 v = half[even_slot(q, cj)];
+    return cj ? make_float2(v.x, -v.y) : v;
+  }
+  static __device__ __forceinline__ float2 load_odd(const float2 *half, int q) { return half[odd_slot(q)]; }
+};
+
 // ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)
 // Forward: Z = FFT_M(x[2n] + i x[2n+1]);  X[k] = E + w^k O,  X[M-k] = conj(E - w^k O),
 //   E = (Z[k] + conj Z[M-k])/2,  O = -i (Z[k] - conj Z[M-k])/2,  w = exp(-i*pi/M).
 // Spectrum layout: out[0] = (X[0], X[M]) (both real), out[k] = X[k] for 0 < k < M.
 // The transform result lives in v[m] = Z[tid + T*m]; only the mirrored half (Z[M-k], owned by thread T-tid) goes
 // through LDS.
-template <class G>
+template <class G, class L = PlainSlots>
 __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], float2 *s, float2 w0, int tid,
                                                        float2 *__restrict__ out) {
   constexpr int M = G::M, T = G::T, E = G::E, H = G::H;
@@ -428,7 +466,7 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], 
     if (m == 0 && k == 0) {
       const float2 z0 = v[0], zh = v[H];  // thread 0 owns Z[0] and Z[M/2]
       out[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
-      out[M / 2] = cconj(zh);
+      L::store_even(out, M / 2, cconj(zh));
     } else {
       const float2 wm = m == 0 ? w0 : cmul(w0, make_float2(pf.c[m], -pf.s[m]));
       const float2 zk = v[m], zm = s[G::pad(M - k)];
@@ -436,8 +474,8 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], 
       const float2 d = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
       const float2 o = make_float2(d.y, -d.x);
       const float2 wo = cmul(wm, o);
-      stream_store<4>(out + k, cadd(e, wo));
-      stream_store<4>(out + (M - k), cconj(csub(e, wo)));
+      L::store_even(out, k, cadd(e, wo));
+      L::store_even(out, M - k, cconj(csub(e, wo)));
     }
   }
 }
@@ -445,13 +483,13 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], 
 // Inverse: from the packed spectrum Y build Z[k] = E + iO (scaled), ready for the inverse passes.
 //   E = (Y[k] + conj Y[M-k])/2, O = conj(w^k) (Y[k] - conj Y[M-k])/2.
 // Split in two so the caller decides what runs while the global loads are in flight.
-template <class G>
+template <class G, class L = PlainSlots>
 __device__ __forceinline__ void real_pack_issue(const float2 *__restrict__ in, float2 (&yk)[G::H], float2 (&ym)[G::H], int tid) {
 #pragma unroll
   for (int m = 0; m < G::H; ++m) {
     const int k = tid + G::T * m;
-    yk[m] = stream_load<2>(in + k);
-    ym[m] = stream_load<2>(in + (k == 0 ? G::M / 2 : G::M - k));
+    yk[m] = k == 0 ? stream_load<2>(in) : L::load_even(in, k);     // slot 0 (packed DC / Nyquist) is slot 0 in every layout
+    ym[m] = L::load_even(in, k == 0 ? G::M / 2 : G::M - k);
   }
 }
 
@@ -482,11 +520,11 @@ __device__ __forceinline__ void real_pack_finish(const float2 (&yk)[G::H], const
   __syncthreads();
 }
 
-template <class G>
+template <class G, class L = PlainSlots>
 __device__ __forceinline__ void real_pack_load_regs(const float2 *__restrict__ in, float2 (&v)[G::E], float2 *s,
                                                     float2 w0, int tid, float scale) {
   float2 yk[G::H], ym[G::H];
-  real_pack_issue<G>(in, yk, ym, tid);
+  real_pack_issue<G, L>(in, yk, ym, tid);
   real_pack_finish<G>(yk, ym, v, s, w0, tid, scale);
 }
 

@@ -1251,7 +1251,8 @@ MacPlan plan_mac(const al_batch *b) {
   else m.tile_code = 80401;
   // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
   if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS)
-    m.moving_code = 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
+    m.moving_code = (b->flags & AL_FLAG_FUSED_MOVING) ? al::moving_fused_code(b)
+                                                      : 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
   m.static_code = m.tile_code;
   if (al::static_mac_active(*b)) {
     const int P = b->n_partitions;
@@ -1441,6 +1442,10 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
 #undef AL_MAC
 #undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
+  if (m.moving_code >= 10000) {
+    if (!al_moving_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_MOVING needs B = 8192 and the split + quad layout flags");
+    return check_error(al::launch_moving_fused(b, stream), "k_moving_fused");
+  }
   if (m.moving_code) {
     const dim3 grid(bins / 256, b->n_capsules, b->n_events);
     if (m.moving_code % 100 == 12)
@@ -1458,6 +1463,12 @@ int al_fused_supported(const al_batch *b) {
   // the fused kernel addresses the signal spectra with 32-bit byte offsets from the workspace base
   return b->log2_block == 13 && b->xspec_zero_block >= 0 && b->xspec_zero_block < 65535 && b->hspec_zero_block >= 0 &&
          b->n_emitters > 0 && b->n_events > 0 && b->n_partitions < 32768;
+}
+
+int al_moving_fused_supported(const al_batch *b) {
+  if (check_batch(b)) return 0;
+  return b->log2_block == 13 && b->n_partitions >= 1 && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS &&
+         (b->flags & AL_FLAG_SPLIT_SPECTRA) && (b->flags & AL_FLAG_QUAD_SPECTRA) && !(b->flags & AL_FLAG_FUSED_STATIC);
 }
 
 int al_mac_synthesis(const al_batch *b, al_stream_t stream) {

@@ -66,9 +66,10 @@ __device__ __forceinline__ void split_odd_input(const float2 (&d)[G::E], float2 
 }
 
 // ------------------------------------------------------------------ 1s. IR partition spectra, split layout
-template <int LOG2M>
+template <int LOG2M, bool QUAD>
 __device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 *s, float *red, int p, int c, int nz) {
   using G = FftGeom<LOG2M - 1, 16>;
+  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   const int tid = threadIdx.x;
   const int n = b.emitter0 + nz;
@@ -111,27 +112,28 @@ __device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 
     split_odd_input<G>(a, u, s, w8, tid);
     fft_regs_to_regs<G, -1>(u, s, tw, tid);
 #pragma unroll
-    for (int i = 0; i < E; ++i) stream_store<4>(out + M + tid + T * i, u[i]);
+    for (int i = 0; i < E; ++i) L::store_odd(out + M, tid + T * i, u[i]);
   }
   fft_regs_to_regs<G, -1>(a, s, tw, tid);
-  real_unpack_store_regs<G>(a, s, tw.w0, tid, out);
+  real_unpack_store_regs<G, L>(a, s, tw.w0, tid, out);
   __syncthreads();   // `red` below shares nothing with the image, but the image's last reads must be over
   float mx = 0.f, zz = 0.f;
   block_reduce3(energy, mx, zz, red, tid, T);
   if (tid == 0) b.ir_energy[blk] = energy;
 }
 
-template <int LOG2M>
+template <int LOG2M, bool QUAD = false>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_ir_spectra_split(al_batch b) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
   __shared__ float red[48];
-  ir_spectra_split_body<LOG2M>(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
+  ir_spectra_split_body<LOG2M, QUAD>(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------ 3s. signal block spectra, split layout
-template <int LOG2M>
+template <int LOG2M, bool QUAD>
 __device__ __forceinline__ void signal_spectra_split_body(const al_batch &b, float2 *s, int jblock, int stream_index) {
   using G = FftGeom<LOG2M - 1, 16>;
+  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   const int tid = threadIdx.x;
   const al_stream st = b.streams[b.stream0 + stream_index];
@@ -187,37 +189,41 @@ __device__ __forceinline__ void signal_spectra_split_body(const al_batch &b, flo
     split_odd_input<G>(h2, u, s, w8, tid);
     fft_regs_to_regs<G, -1>(u, s, tw, tid);
 #pragma unroll
-    for (int i = 0; i < E; ++i) out[M + tid + T * i] = u[i];
+    for (int i = 0; i < E; ++i) {
+      if constexpr (QUAD) L::store_odd(out + M, tid + T * i, u[i]);
+      else out[M + tid + T * i] = u[i];
+    }
   }
   fft_regs_to_regs<G, -1>(h1, s, tw, tid);
-  real_unpack_store_regs<G>(h1, s, tw.w0, tid, out);
+  real_unpack_store_regs<G, L>(h1, s, tw.w0, tid, out);
 }
 
-template <int LOG2M>
+template <int LOG2M, bool QUAD = false>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_signal_spectra_split(al_batch b) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
-  signal_spectra_split_body<LOG2M>(b, s, blockIdx.x, blockIdx.y);
+  signal_spectra_split_body<LOG2M, QUAD>(b, s, blockIdx.x, blockIdx.y);
 }
 
 // Both forward transforms in ONE launch (they are independent): the 1 536 signal windows of a cfg2 scene are a 0.05 ms
 // kernel of their own otherwise, too short to fill the chip.  Workgroup ids [0, n_sig) are signal jobs, the rest IR jobs.
-template <int LOG2M>
+template <int LOG2M, bool QUAD = false>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_forward_spectra_split(al_batch b, int n_sig) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
   __shared__ float red[48];
   const int id = blockIdx.x;
   if (id < n_sig) {
-    signal_spectra_split_body<LOG2M>(b, s, id % b.max_nj, id / b.max_nj);
+    signal_spectra_split_body<LOG2M, QUAD>(b, s, id % b.max_nj, id / b.max_nj);
   } else {
     const int q = id - n_sig, pc = b.n_partitions * b.n_capsules;
-    ir_spectra_split_body<LOG2M>(b, s, red, q % b.n_partitions, (q / b.n_partitions) % b.n_capsules, q / pc);
+    ir_spectra_split_body<LOG2M, QUAD>(b, s, red, q % b.n_partitions, (q / b.n_partitions) % b.n_capsules, q / pc);
   }
 }
 
 // ------------------------------------------------------------------ 5s. block synthesis, split layout
-template <int LOG2M>
+template <int LOG2M, bool QUAD = false>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_block_synthesis_split(al_batch b) {
   using G = FftGeom<LOG2M - 1, 16>;
+  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   constexpr HalfTurnFactors<G> hf{};
   __shared__ float2 s[G::LDS_ELEMS];
@@ -253,9 +259,9 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
     const float scale = 0.5f / (float)M;            // 1/(B/2) of each half-size inverse, and the 1/2 of (s - d)/2
     float2 u[E];
 #pragma unroll
-    for (int i = 0; i < E; ++i) u[i] = stream_load<2>(y + M + tid + T * i);   // odd half, requested first
+    for (int i = 0; i < E; ++i) u[i] = L::load_odd(y + M, tid + T * i);   // odd half, requested first
     float2 v[E];
-    real_pack_load_regs<G>(y, v, s, tw.w0, tid, scale);
+    real_pack_load_regs<G, L>(y, v, s, tw.w0, tid, scale);
     fft_regs_to_regs<G, 1>(v, s, tw, tid);          // v[i] = (s[2m], s[2m+1]) / 2, m = tid + T*i
 #pragma unroll
     for (int i = 0; i < E; ++i) u[i] = make_float2(u[i].x * scale, u[i].y * scale);

@@ -215,11 +215,16 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
 
 }  // namespace al
 #include "al_split.h"
+#include "al_quad.h"
 namespace al {
 
 // ------------------------------------------------------------------ launchers
 #define AL_DISPATCH_SPLIT(b, KERNEL, GRID, ...)                                                                          \
   do {                                                                                                                  \
+    if (((b)->flags & AL_FLAG_QUAD_SPECTRA) && (b)->log2_block == 13) {   /* quad layout: B = 8192 only */              \
+      hipLaunchKernelGGL((KERNEL<13, true>), GRID, dim3(FftGeom<12, 16>::T), 0, stream, __VA_ARGS__);                   \
+      break;                                                                                                            \
+    }                                                                                                                   \
     switch ((b)->log2_block) {                                                                                          \
       case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, dim3(FftGeom<10, 16>::T), 0, stream, __VA_ARGS__); break;         \
       case 12: hipLaunchKernelGGL((KERNEL<12>), GRID, dim3(FftGeom<11, 16>::T), 0, stream, __VA_ARGS__); break;         \

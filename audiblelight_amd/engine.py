@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _hip
-from .plan import BatchPlan, MixPlan
+from .plan import SPARSE_MAX_PARTITIONS, BatchPlan, MixPlan
 
 
 def _debug_flags() -> int:
@@ -447,6 +447,15 @@ class Renderer:
             tables += [np.array([src.prescale for src in sources], dtype=np.float32),
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
         parts = plan.emitter_parts() if os.environ.get("AL_TRIM_PARTITIONS", "1") == "1" else None
+        # Sliding-window moving events through k_moving_fused (csrc/al_quad.h): the accumulate transforms the IR partitions
+        # itself, their spectra are never written (cfg3: 36 -> 17 GB per scene).  Needs the split + quad layout (B = 8192).
+        fused_static = os.environ.get("AL_FUSED", "0") == "1"
+        fuse_moving = (os.environ.get("AL_FUSED_MOVING", "1") == "1" and plan.log2_block == 13 and not fused_static
+                       and os.environ.get("AL_SPLIT", "1") == "1" and 1 <= P <= SPARSE_MAX_PARTITIONS)
+        fused_parts = plan.fused_moving_parts(parts) if fuse_moving else None
+        fuse_moving = fused_parts is not None
+        if fuse_moving:
+            parts = fused_parts
         if parts is not None:        # al_batch.emitter_parts: IR partitions that cannot reach a kept block are not transformed
             tables.append(parts)
         tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]
@@ -488,6 +497,10 @@ class Renderer:
         if want_split and plan.log2_block >= 11:
             for desc in descs:
                 desc.flags |= _hip.FLAG_SPLIT_SPECTRA
+                if fuse_moving:
+                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
+                elif plan.log2_block == 13 and os.environ.get("AL_QUAD", "0") == "1":   # A/B + test switch: the quad layout alone
+                    desc.flags |= _hip.FLAG_QUAD_SPECTRA
         # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes
         # the Y round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
         if fused and not (want_split and plan.log2_block >= 11):

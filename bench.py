@@ -112,7 +112,7 @@ def _cpu_scene_worker(job):
     return time.perf_counter() - t0, work
 
 
-def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, n_irs_cap=8):
+def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, n_irs_cap=8, max_events=None):
     """the oracle on every physical core of the host, ONE PROCESS PER SCENE (scenes are independent; the
     reference's dataset loop is serial, scripts/generate/benchmark.py:44-77): `workers` different scenes rendered at once,
     mixdown and per-event padded copies included.  rate = scenes x scene seconds / wall time of the slowest worker."""
@@ -122,7 +122,12 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
     from audiblelight_amd import synthetic
 
     cfg = synthetic.CONFIGS[config]
-    max_events = {"cfg3": 1, "cfg5": 2}.get(config, 0)
+    if max_events is None:
+        # measured in full once (profiles/r04a_bench_cfg2_allcores_full.json: 128 cores x one whole cfg2 scene each took 400-536 s
+        # per scene against 14 s for one process alone -- 128 processes share the memory system -- i.e. 14.3 scene-s/s); the
+        # default run renders 6 of the 64 events per scene, every core busy for the whole sample, and scales by the event count
+        max_events = {"cfg2": 6, "cfg3": 1, "cfg4": 6, "cfg5": 2}.get(config, 0)
+    max_events = min(max_events, cfg["E"]) if max_events else 0
     duration = cfg["T"] * scale
     jobs = [(config, 10_000 + i, scale, max_events, n_irs_cap) for i in range(workers)]
     # spawn, not fork: a broken worker raises instead of hanging.  Started BEFORE this process initialises the GPU.
@@ -141,7 +146,7 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
                 sample=f"{workers} different {config} scenes at once, one oracle process per scene on one physical core each: "
                        + (f"all {full_events} events" if not extrapolated else
                           f"{max_events} of {full_events} events" + (f" with {n_irs_cap} IRs each" if config == "cfg3" else "")
-                          + ", scaled linearly in events x IRs")
+                          + ", scaled linearly in events x IRs (--cpu-scene-events 0 renders whole scenes: minutes)")
                        + " + float32 mixdown + the reference's per-event padded copies; rate from the slowest worker")
 
 
@@ -367,6 +372,9 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=-1, metavar="N",
                     help="also time the oracle on N host processes at once, one whole scene each (all-cores CPU figure; -1 = one per "
                          "PHYSICAL core, bounded by free memory; 0 = skip; skipped by itself under a profiler)")
+    ap.add_argument("--cpu-scene-events", type=int, default=-1, metavar="N",
+                    help="events of every scene the all-cores leg renders (-1: a bounded sample, 6 for cfg2; 0: the whole scene, "
+                         "which takes 128 busy cores about nine minutes at cfg2)")
     ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
                     help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; "
                          "default 16 on one GPU, 0 otherwise)")
@@ -425,7 +433,8 @@ def main():
                 workers = max(1, min(workers, int(0.5 * avail / per)))
             except (OSError, StopIteration, ValueError):
                 pass
-            all_cores = cpu_baseline_all_cores(args.config, args.scale, workers, how, cfg["E"], cfg["E"] * cfg["N"])
+            all_cores = cpu_baseline_all_cores(args.config, args.scale, workers, how, cfg["E"], cfg["E"] * cfg["N"],
+                                               max_events=None if args.cpu_scene_events < 0 else (args.cpu_scene_events or cfg["E"]))
 
     import torch
 

@@ -51,7 +51,7 @@ GLDS_CASES += [("glds_cfg2_shape", 3121204, 23.44, 11.72, 5, 2), ("glds_ragged_s
 # k_spectral_mac_static_lds<12,{7,8},2>: 13..16 partitions for a caller that gave no all-zero block (hspec_zero_block = -1)
 NO_ZERO_BLOCK_CASES = [(f"no_zero_block_P{P}", 3120000 + 100 * P + 3, 20.6, P - 0.37, 2, 1) for P in (13, 14, 15, 16)]
 MOVING_CODES = [612, 624]       # asserted by test_moving_regimes / test_cfg3_regime_all_rows
-FUSED_MOVING_CODES = []         # the IR-transform-fused sliding-window kernel (filled in where it is the default)
+FUSED_MOVING_CODES = [10508, 10604]   # k_moving_fused<5,8> / <6,4> (csrc/al_quad.h): default for sliding-window moving events at B = 8192
 # codes the GPU tests assert beyond the tables above: cfg4's <12,6,2>, cfg5's tile kernel with two full partition tiles
 EXTRA_STATIC_CODES = [3120602, 1121202]
 
@@ -60,6 +60,9 @@ def codes_of_kernel_symbol(sym: str):
     """Demangled kernel name (``nm -C``) -> the al_spectral_mac_variant codes under which it runs, as (kind, code) pairs."""
     import re
 
+    f = re.search(r"k_moving_fused<([0-9]+), ([0-9]+)>", sym)
+    if f:
+        return [("moving", 10000 + 100 * int(f.group(1)) + int(f.group(2)))]
     m = re.search(r"k_spectral_mac(_static_lds|_static_glds|_static|_moving)?<([0-9, a-z]+)>", sym)
     if not m:
         return []
@@ -87,7 +90,7 @@ def asserted_codes():
     """Every (kind, code) some -m gpu test asserts through al_spectral_mac_variant."""
     out = {("static", c[1]) for c in STATIC_CASES} | {("static", c[1]) for c in STATIC_LOOP_CASES} | {("static", c[1]) for c in GLDS_CASES}
     out |= {("static", c[1]) for c in NO_ZERO_BLOCK_CASES}
-    out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES}
+    out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES + FUSED_MOVING_CODES}
     return out
 
 
@@ -174,12 +177,18 @@ def run_moving_case(renderer, log2_block, p_mult, n_irs, k_mult, expect_moving, 
     batch = renderer.prepare(pl, clips, mic_ir)
     _, moving = mac_codes(renderer, batch)
     assert moving == expect_moving, moving
+    fused = expect_moving >= 10000      # k_moving_fused (csrc/al_quad.h): the IR spectra are never written at all
     if expect_moving:
         assert all(int(r) == 1 for r in pl.events["reserved"]), "planner did not flag the events for the sliding window"
         # al_batch.emitter_parts: partitions that only reach blocks past the clip's end are neither transformed nor read.  The
         # spectra workspace is poisoned first, so a read of a block that was not written would turn the event into NaNs.
         parts = pl.emitter_parts()
-        assert parts is not None and 0 <= parts.min() < pl.n_partitions and parts.max() <= pl.n_partitions
+        assert fused or (parts is not None and 0 <= parts.min() < pl.n_partitions and parts.max() <= pl.n_partitions)
+        if fused:
+            parts = pl.fused_moving_parts(parts)
+            assert (parts == 0).all()
+            from audiblelight_amd import _hip
+            assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA and batch.descs[0].flags & _hip.FLAG_FUSED_MOVING
         assert batch.descs[0].emitter_parts, "the planner's table did not reach the descriptor"
         n_real = pl.hspec_blocks * B * 2
         batch.bufs["hspec"][:n_real] = float("nan")

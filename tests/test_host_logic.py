@@ -305,7 +305,8 @@ def test_every_accumulate_instantiation_is_named_by_a_gpu_test():
     from tests import mac_regimes as mr
 
     out = subprocess.check_output(["nm", "-C", _hip.DEFAULT_LIB]).decode()
-    syms = {line.split(" ", 2)[2] for line in out.splitlines() if "k_spectral_mac" in line and "__device_stub__" not in line}
+    syms = {line.split(" ", 2)[2] for line in out.splitlines()
+            if ("k_spectral_mac" in line or "k_moving_fused" in line) and "__device_stub__" not in line}
     assert len(syms) >= 40                                  # 12 x {one k-tile, pair, LDS ring} + 2 two-unit + tile + moving kernels
     asserted, unpinned = mr.asserted_codes(), []
     for sym in sorted(syms):

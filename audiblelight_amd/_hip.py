@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
-ABI_VERSION = 4   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
+ABI_VERSION = 5   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
 FLAG_FUSED_STATIC = 2
@@ -78,6 +78,24 @@ class AlMix(_Versioned):
     ]
 
 
+class AlEventSpec(ct.Structure):      # al_event_spec
+    _fields_ = [("n_samples", ct.c_int32), ("n_emitters", ct.c_int32), ("emitter0", ct.c_int32), ("is_moving", ct.c_int32),
+                ("snr", ct.c_float), ("ref_db", ct.c_float), ("gain", ct.c_float), ("stft_len", ct.c_int32), ("duration", ct.c_double)]
+
+
+class AlPlanInfo(ct.Structure):       # al_plan_info
+    _fields_ = [(n, ct.c_int32) for n in ("log2_block", "n_capsules", "ir_len", "n_events", "n_streams", "n_emitters", "n_partitions",
+                                          "hop", "fft_size", "max_blocks", "max_nj", "max_nj_sliding", "xspec_blocks", "yspec_blocks",
+                                          "n_partials", "reserved")] + \
+               [(n, ct.c_int64) for n in ("hspec_blocks", "audio_floats", "spatial_floats", "wtab_floats")]
+
+
+class AlMixTables(ct.Structure):      # al_mix_tables
+    _fields_ = [(n, ct.c_int32) for n in ("n_capsules", "n_samples", "tile", "n_tiles", "n_slots", "n_tile_events", "n_skipped", "reserved")] + \
+               [(n, ct.c_void_p) for n in ("tile_ptr", "tile_events", "slot_src", "slot_len", "slot_start", "slot_count", "slot_rows",
+                                           "slot_event", "skipped")]
+
+
 class HipError(RuntimeError):
     """A C-ABI call returned a negative status."""
 
@@ -99,6 +117,25 @@ SYMBOLS = {
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "al_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
     "al_moving_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
+    "al_plan_last_error": (ct.c_char_p, []),
+    "al_choose_log2_block": (ct.c_int32, [ct.c_int32, ct.c_int32]),
+    "al_stft_frame_count": (ct.c_int32, [ct.c_int64, ct.c_int32]),
+    "al_interpolation_rows": (ct.c_int32, [ct.c_int32, ct.c_double, ct.c_double, ct.c_int32]),
+    "al_interpolation_matrix": (ct.c_int, [ct.c_int32, ct.c_double, ct.c_double, ct.c_int32, ct.c_int32, _P]),
+    "al_plan_create": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_double, ct.c_int32, ct.c_int32, ct.c_int32, ct.c_int32,
+                                  ct.POINTER(ct.c_void_p)]),
+    "al_plan_destroy": (None, [_P]),
+    "al_plan_get_info": (ct.c_int, [_P, ct.POINTER(AlPlanInfo)]),
+    "al_plan_events": (ct.c_void_p, [_P]),
+    "al_plan_streams": (ct.c_void_p, [_P]),
+    "al_plan_wtab": (ct.c_void_p, [_P]),
+    "al_plan_audio_offsets": (ct.c_void_p, [_P]),
+    "al_workspace_bytes": (ct.c_int64, [_P]),
+    "al_plan_emitter_parts": (ct.c_int, [_P, ct.c_int32, _P]),
+    "al_plan_mixdown": (ct.c_int, [_P, _P, _P, _P, _P, _P, ct.c_int32, ct.c_double, ct.c_double, ct.c_int32, ct.c_int32,
+                                   ct.POINTER(ct.c_void_p)]),
+    "al_mix_plan_destroy": (None, [_P]),
+    "al_mix_plan_get": (ct.c_int, [_P, ct.POINTER(AlMixTables)]),
     "al_mac_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
@@ -170,7 +207,8 @@ class Library:
     def call(self, name: str, *args):
         rc = getattr(self, "_" + name)(*args)
         if isinstance(rc, int) and rc < 0 and SYMBOLS[name][0] is ct.c_int:
-            raise HipError(f"{name} failed ({rc}): {self.last_error()}")
+            planner = name.startswith(("al_plan", "al_mix_plan", "al_interpolation"))   # csrc/al_plan.cpp keeps its own message
+            raise HipError(f"{name} failed ({rc}): {(self._al_plan_last_error() or b'').decode() if planner else self.last_error()}")
         return rc
 
 

@@ -35,6 +35,12 @@
 #include "al_common.h"
 #include "al_fft.h"
 
+// Timing builds (profiles/tools/build_defs.sh): bit 0 no raw loads (the fold gets lane-made values), bit 1 no transform passes,
+// bit 2 no products, bit 3 no LDS stage traffic, bit 4 no look-ahead (every round requests its own samples).  0 = the product.
+#ifndef AL_MF_SKIP
+#define AL_MF_SKIP 0
+#endif
+
 namespace al {
 
 // a += x * h (complex) as two v_pk_fma_f32 (see cfma_packed in al_kernels.hip: no swizzled operand copies in registers)
@@ -66,11 +72,38 @@ struct FoldFactors {
   }
 };
 
-// The Q-point transform input of tile `tile` for one partition: z[m] at n = tg + 128 m.  `ir` points at the partition's first
-// sample, `remaining` = samples left in the IR from there (zeros beyond); `live` = false gives zeros without touching memory.
+// The raw samples a tile's fold needs from one partition, requested as early as possible (a round before they are folded):
+// 64 floats per thread.  Tile 0 folds pairs (h[2n], h[2n+1]) and (h[2n + 2Q], h[2n + 2Q + 1]), n = tg + 128 m; tiles 1..3 fold
+// h[n + Q j], j < 4.  `ir` points at the partition's first sample, `remaining` = samples left in the IR from there (the loads
+// are clamped into the row, the fold zeroes what lies beyond); `live` = false touches no memory.
+template <bool TILE0>
+__device__ __forceinline__ void issue_raw(const float *__restrict__ ir, int remaining, bool live, int tg, float (&raw)[64]) {
+  constexpr int Q = 2048;
+  if (!live) return;
+  const bool whole = remaining >= 4 * Q;   // group-uniform
+  const int last = remaining - 1;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if constexpr (TILE0) {
+      const int t = 2 * (tg + 128 * m);
+      if (whole) {
+        const float2 lo = *reinterpret_cast<const float2 *>(ir + t), hi = *reinterpret_cast<const float2 *>(ir + t + 2 * Q);
+        raw[4 * m] = lo.x; raw[4 * m + 1] = lo.y; raw[4 * m + 2] = hi.x; raw[4 * m + 3] = hi.y;
+      } else {
+        raw[4 * m] = ir[min(t, last)]; raw[4 * m + 1] = ir[min(t + 1, last)];
+        raw[4 * m + 2] = ir[min(t + 2 * Q, last)]; raw[4 * m + 3] = ir[min(t + 2 * Q + 1, last)];
+      }
+    } else {
+      const int n = tg + 128 * m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) raw[4 * m + j] = whole ? ir[n + Q * j] : ir[min(n + Q * j, last)];
+    }
+  }
+}
+
+// The Q-point transform input of tile TILE from those samples: z[m] at n = tg + 128 m.
 template <int TILE>
-__device__ __forceinline__ void fold_partition(const float *__restrict__ ir, int remaining, bool live, int tg, float2 wb,
-                                               float2 (&z)[16]) {
+__device__ __forceinline__ void fold_raw(const float (&raw)[64], int remaining, bool live, int tg, float2 wb, float2 (&z)[16]) {
   constexpr int Q = 2048;
   constexpr FoldFactors ff{};
   constexpr float R2 = 0.70710678118654752440f;
@@ -79,33 +112,21 @@ __device__ __forceinline__ void fold_partition(const float *__restrict__ ir, int
     for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
     return;
   }
-  const bool whole = remaining >= 4 * Q;   // group-uniform
+  const bool whole = remaining >= 4 * Q;
   const int last = remaining - 1;
-  if constexpr (TILE == 0) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int t = 2 * (tg + 128 * m);
-      float2 lo, hi;
-      if (whole) {
-        lo = *reinterpret_cast<const float2 *>(ir + t);
-        hi = *reinterpret_cast<const float2 *>(ir + t + 2 * Q);
-      } else {
-        const float a0 = ir[min(t, last)], a1 = ir[min(t + 1, last)], b0 = ir[min(t + 2 * Q, last)], b1 = ir[min(t + 2 * Q + 1, last)];
-        lo = make_float2(t <= last ? a0 : 0.f, t + 1 <= last ? a1 : 0.f);
-        hi = make_float2(t + 2 * Q <= last ? b0 : 0.f, t + 2 * Q + 1 <= last ? b1 : 0.f);
+  for (int m = 0; m < 16; ++m) {
+    float h0 = raw[4 * m], h1 = raw[4 * m + 1], h2 = raw[4 * m + 2], h3 = raw[4 * m + 3];
+    if constexpr (TILE == 0) {
+      if (!whole) {
+        const int t = 2 * (tg + 128 * m);
+        h0 = t <= last ? h0 : 0.f; h1 = t + 1 <= last ? h1 : 0.f; h2 = t + 2 * Q <= last ? h2 : 0.f; h3 = t + 2 * Q + 1 <= last ? h3 : 0.f;
       }
-      z[m] = make_float2(lo.x + hi.x, lo.y + hi.y);
-    }
-  } else {
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
+      z[m] = make_float2(h0 + h2, h1 + h3);
+    } else {
       const int n = tg + 128 * m;
-      float h0, h1, h2, h3;
-      if (whole) {
-        h0 = ir[n]; h1 = ir[n + Q]; h2 = ir[n + 2 * Q]; h3 = ir[n + 3 * Q];
-      } else {
-        const float a0 = ir[min(n, last)], a1 = ir[min(n + Q, last)], a2 = ir[min(n + 2 * Q, last)], a3 = ir[min(n + 3 * Q, last)];
-        h0 = n <= last ? a0 : 0.f; h1 = n + Q <= last ? a1 : 0.f; h2 = n + 2 * Q <= last ? a2 : 0.f; h3 = n + 3 * Q <= last ? a3 : 0.f;
+      if (!whole) {
+        h0 = n <= last ? h0 : 0.f; h1 = n + Q <= last ? h1 : 0.f; h2 = n + 2 * Q <= last ? h2 : 0.f; h3 = n + 3 * Q <= last ? h3 : 0.f;
       }
       const float2 w = cmul(wb, make_float2(ff.c[m], -ff.s[m]));    // e^{-i pi n / B}
       const float2 w2 = cmul(w, w);
@@ -148,6 +169,7 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + tile * Q + 4 * tid;
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + (int64_t)c * K) * B + tile * Q + 4 * tid;
   const bool bin0 = tile == 0 && tid == 0;
+  const bool bin0_wave = tile == 0 && tid < 64;   // wave-uniform: only that wave pays for the (DC, Nyquist) slot's select
 
   auto load4 = [](const float2 *p) {
     Quad4 v;
@@ -170,7 +192,10 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
     const bool first = p0 == 0;     // later passes add to what the earlier ones stored
     Quad4 acc[W];
     int kbase = -1;                 // output block held in acc[0]; -1: the window has not been placed yet
+    float raw[64];                  // the samples of the round after the one being transformed (issue_raw)
+    bool prefetched = false;
     for (int l0 = 0; l0 < ev.n_streams; l0 += 64) {
+      prefetched = false;           // the look-ahead stops at the end of a table chunk
       __syncthreads();
       if (tid < 64 && l0 + tid < ev.n_streams) {
         const al_stream st = b.streams[ev.stream0 + l0 + tid];
@@ -208,7 +233,7 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) x[jj].s[i] = make_float2(x[jj].s[i].x * sc, x[jj].s[i].y * sc);
         }
-        const float *irn = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)t.z * b.ir_stride_n;
+        const float *irc = b.ir + (int64_t)c * b.ir_stride_c;
         static_for<ROUNDS>([&](auto r_c) {
           constexpr int r = decltype(r_c)::value;
           if (p0 + 4 * r < pe) {                          // workgroup-uniform: the round has a live partition
@@ -220,32 +245,74 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
             tw.hide_from_hoisting();
             const int p = p0 + 4 * r + g;                 // this group's partition
             const bool live = p < pe;                     // group-uniform
-            float2 z[16];
-            const float *src = irn + (int64_t)min(p, P - 1) * B;
             const int remaining = b.ir_len - min(p, P - 1) * B;
-            switch (tile) {                               // workgroup-uniform
-              case 0: fold_partition<0>(src, remaining, live, tg, wb, z); break;
-              case 1: fold_partition<1>(src, remaining, live, tg, wb, z); break;
-              case 2: fold_partition<2>(src, remaining, live, tg, wb, z); break;
-              default: fold_partition<3>(src, remaining, live, tg, wb, z); break;
+            if (!prefetched) {                            // first round of a table chunk: nobody requested its samples yet
+              const float *src = irc + (int64_t)t.z * b.ir_stride_n + (int64_t)min(p, P - 1) * B;
+              if (tile == 0) issue_raw<true>(src, remaining, live, tg, raw);
+              else issue_raw<false>(src, remaining, live, tg, raw);
             }
-            fft_regs_to_regs<G, -1>(z, img[g], tw, tg);   // z[m] = Z[tg + 128 m]; its last LDS reads end with a barrier
-            if (tile == 0) {
-              real_unpack_store_regs<G>(z, img[g], tw.w0, tg, stage[g]);
-            } else {
+            float2 z[16];
+            if (AL_MF_SKIP & 1) {
 #pragma unroll
-              for (int m = 0; m < 16; ++m) stage[g][tg + 128 * m] = z[m];
+              for (int m = 0; m < 16; ++m) z[m] = make_float2(wb.x * (float)(m + p), wb.y - (float)remaining);
+            } else {
+              switch (tile) {                             // workgroup-uniform
+                case 0: fold_raw<0>(raw, remaining, live, tg, wb, z); break;
+                case 1: fold_raw<1>(raw, remaining, live, tg, wb, z); break;
+                case 2: fold_raw<2>(raw, remaining, live, tg, wb, z); break;
+                default: fold_raw<3>(raw, remaining, live, tg, wb, z); break;
+              }
+            }
+            if (!(AL_MF_SKIP & 2)) fft_regs_to_regs<G, -1>(z, img[g], tw, tg);   // z[m] = Z[tg + 128 m]; its last LDS reads end with a barrier
+            if (!(AL_MF_SKIP & 8)) {
+              if (tile == 0 && !(AL_MF_SKIP & 2)) {
+                real_unpack_store_regs<G>(z, img[g], tw.w0, tg, stage[g]);
+              } else {
+#pragma unroll
+                for (int m = 0; m < 16; ++m) stage[g][tg + 128 * m] = z[m];
+              }
+            }
+            // The NEXT round's samples are requested now and folded a whole accumulate phase later: with one workgroup per CU
+            // and every wave in the same phase nothing else would hide their latency (profiles/r04c_moving_fused_phase_timing.txt:
+            // the loads alone were 2.7 of the first version's 6.9 ms).  Next round = this stream's (r + 1) or the first round of
+            // the next stream of this table chunk that has a partition in this pass.
+            {
+              int nemit = t.z, np_ = p0 + 4 * (r + 1) + g, npe = pe;
+              bool found = (r + 1 < ROUNDS) && (p0 + 4 * (r + 1) < pe);
+              if (!found) {
+                for (int l2 = l + 1; l2 < nl; ++l2) {
+                  const int4 t2 = tab[l2];
+                  const int pe2 = min(min(P, K - t2.x), p0 + PTW);
+                  if (t2.y > 0 && pe2 > p0) { found = true; nemit = t2.z; np_ = p0 + g; npe = pe2; break; }
+                }
+              }
+              prefetched = found && !(AL_MF_SKIP & 16);
+              if (prefetched) {
+                const float *src = irc + (int64_t)nemit * b.ir_stride_n + (int64_t)min(np_, P - 1) * B;
+                const int rem2 = b.ir_len - min(np_, P - 1) * B;
+                const int tg2 = opaque_lane(tg0);
+                if (tile == 0) issue_raw<true>(src, rem2, np_ < npe, tg2, raw);
+                else issue_raw<false>(src, rem2, np_ < npe, tg2, raw);
+              }
             }
             __syncthreads();
             static_for<4>([&](auto gg_c) {
               constexpr int gg = decltype(gg_c)::value, pp = 4 * r + gg;
               if (p0 + pp < pe) {                         // workgroup-uniform
-                const Quad4 h = load4(&stage[gg][4 * tid]);
+                Quad4 h;
+                if (AL_MF_SKIP & 8) {
+                  const float2 zz = make_float2((float)tid, 1.f);
+                  h.s[0] = h.s[1] = h.s[2] = h.s[3] = zz;
+                } else {
+                  h = load4(&stage[gg][4 * tid]);
+                }
 #pragma unroll
                 for (int jj = 0; jj < NJW; ++jj) {
-                  if (bin0) {                             // (DC, Nyquist) packed in slot 0 of tile 0: two real products
-                    acc[jj + pp].s[0].x = fmaf(x[jj].s[0].x, h.s[0].x, acc[jj + pp].s[0].x);
-                    acc[jj + pp].s[0].y = fmaf(x[jj].s[0].y, h.s[0].y, acc[jj + pp].s[0].y);
+                  if ((AL_MF_SKIP & 4) || jj >= nj) continue;   // workgroup-uniform: blocks past the stream's last are not multiplied
+                  if (bin0_wave) {                        // (DC, Nyquist) packed in slot 0 of tile 0: two real products in lane 0
+                    const float2 a0 = acc[jj + pp].s[0];
+                    cfma_pk(acc[jj + pp].s[0], x[jj].s[0], h.s[0]);
+                    if (bin0) acc[jj + pp].s[0] = make_float2(fmaf(x[jj].s[0].x, h.s[0].x, a0.x), fmaf(x[jj].s[0].y, h.s[0].y, a0.y));
                   } else {
                     cfma_pk(acc[jj + pp].s[0], x[jj].s[0], h.s[0]);
                   }
@@ -255,7 +322,7 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
                 }
               }
             });
-            __syncthreads();                              // the stage is free for the next round's transforms
+            // no barrier here: the next write of the stage lies behind the barriers of the next round's transform passes
           }
         });
       }

@@ -2,18 +2,35 @@
 
 Turns "events of one microphone" (clip lengths, emitter columns, SNRs, trajectories) into the
 tables the kernels read (``al_event`` / ``al_stream`` of include/audiblelight_hip.h), the
-workspace sizes, and the mixdown slot/tile lists.  Everything here is cheap numpy on shapes;
-the samples themselves never pass through this module.
+workspace sizes, and the mixdown slot/tile lists.  The arithmetic itself lives BEHIND the C ABI
+(csrc/al_plan.cpp: al_plan_create, al_plan_emitter_parts, al_workspace_bytes, al_plan_mixdown,
+al_interpolation_matrix), so a host in another language gets the same tables; this module is
+the ctypes caller that wraps them as numpy arrays.  The samples never pass through here.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
+import ctypes as ct
+
 import numpy as np
 
-from . import config
+from . import _hip, config
 from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
+
+
+def _lib():
+    return _hip.get_library()
+
+
+def _copy(ptr, n, dtype):
+    """A numpy copy of ``n`` items of ``dtype`` behind a host pointer the planner library owns."""
+    n = int(n)
+    if n <= 0 or not ptr:
+        return np.zeros(0, dtype=dtype)
+    nbytes = n * np.dtype(dtype).itemsize
+    return np.frombuffer(ct.string_at(ptr, nbytes), dtype=dtype).copy()
 
 
 SPARSE_MAX_NJ = 6  # AL_SPARSE_MAX_NJ of include/audiblelight_hip.h
@@ -31,20 +48,31 @@ def generate_interpolation_matrix(ir_times: np.ndarray, sr=config.SAMPLE_RATE, h
     Same contract as the reference's ``generate_interpolation_matrix`` (synthesize.py:148-181):
     IR ``l`` starts at frame ``round((t_l*sr + hop)/hop)`` and fades linearly into IR ``l+1``.
     """
-    first = np.round((np.asarray(ir_times, dtype=np.float64) * sr + hop_size) / hop_size)
-    rows = int(first[-1]) if n_frames is None else int(n_frames)
-    weights = np.zeros((rows, len(first)))
-    for l in range(len(first) - 1):
-        idx = np.arange(first[l], first[l + 1] + 1, dtype=int) - 1
-        up = np.linspace(0.0, 1.0, len(idx))
-        weights[idx, l] = 1.0 - up
-        weights[idx, l + 1] = up
+    times = np.asarray(ir_times, dtype=np.float64)
+    n = len(times)
+    uniform = n >= 1 and times[0] == 0.0 and np.array_equal(times, np.linspace(0.0, times[-1], n))
+    if not uniform:      # arbitrary IR times (the render path only ever asks for linspace(0, duration, n)): same rule, in numpy
+        first = np.round((times * sr + hop_size) / hop_size)
+        rows = int(first[-1]) if n_frames is None else int(n_frames)
+        weights = np.zeros((rows, n))
+        for l in range(n - 1):
+            idx = np.arange(first[l], first[l + 1] + 1, dtype=int) - 1
+            up = np.linspace(0.0, 1.0, len(idx))
+            keep = (idx >= 0) & (idx < rows)
+            weights[idx[keep], l] = 1.0 - up[keep]
+            weights[idx[keep], l + 1] = up[keep]
+        return weights
+    lib = _lib()
+    duration = float(times[-1])
+    rows = lib.call("al_interpolation_rows", n, duration, float(sr), int(hop_size)) if n_frames is None else int(n_frames)
+    weights = np.zeros((max(rows, 0), n), dtype=np.float64)
+    lib.call("al_interpolation_matrix", n, duration, float(sr), int(hop_size), int(rows), weights.ctypes.data)
     return weights
 
 
 def stft_frame_count(n_samples: int, hop_size: int = config.HOP_SIZE) -> int:
     """Frames the reference STFT produces for n_samples (synthesize.py:123)."""
-    return 2 * int(np.ceil(n_samples / (2.0 * hop_size))) + 1
+    return int(_lib().call("al_stft_frame_count", int(n_samples), int(hop_size)))
 
 
 @dataclass
@@ -78,6 +106,9 @@ class BatchPlan:
     n_partials: int              # entries of 4 floats
     hop: int = config.HOP_SIZE
     fft_size: int = config.FFT_SIZE
+    _specs: Optional[list] = None        # what plan_batch was given (the C planner is re-run from it for the derived tables)
+    _sample_rate: float = 0.0
+    _win: int = config.WIN_SIZE
 
     @property
     def block(self) -> int:
@@ -91,43 +122,44 @@ class BatchPlan:
     def hspec_blocks(self) -> int:
         return self.n_emitters * self.n_capsules * self.n_partitions
 
+    def _c_plan(self):
+        """The C planner's own object for this batch (rebuilt from the specs: the tables above are copies of its arrays)."""
+        if self._specs is None:
+            raise ValueError("this BatchPlan was not made by plan_batch")
+        return _create_c_plan(self._specs, self.n_capsules, self.ir_len, self._sample_rate, self.log2_block, self.hop,
+                              self._win, self.fft_size)
+
+    def _parts(self, fused_moving: bool) -> Optional[np.ndarray]:
+        if not len(self.events) or self.n_emitters <= 0:
+            return None
+        lib, handle = _lib(), self._c_plan()
+        try:
+            out = np.zeros(self.n_emitters, dtype=np.int32)
+            have = lib.call("al_plan_emitter_parts", handle, 1 if fused_moving else 0, out.ctypes.data)
+            return out if have == 1 else None
+        finally:
+            lib.call("al_plan_destroy", handle)
+
     def emitter_parts(self) -> Optional[np.ndarray]:
         """al_batch.emitter_parts: per IR column, how many leading partitions can reach a block its event keeps (None: every
         partition of every IR).  pad_or_truncate_audio (synthesize.py:590) drops the convolution's tail from block n_blocks
         on, and partition p of an IR whose signal starts at block j_lo only feeds blocks >= j_lo + p.  Only the IRs of
         sliding-window moving events (al_event.reserved == 1: the one accumulate that honours it) get fewer than P; a
-        column shared by several streams keeps the largest demand."""
-        P = self.n_partitions
-        if (P <= 1 or P > SPARSE_MAX_PARTITIONS or not len(self.streams) or not len(self.events)
-                or not (self.events["reserved"] == 1).any()):
-            return None
-        st, ev = self.streams, self.events
-        real = (ev["n_streams"][st["event"]] > 0) & (st["emitter"] >= 0) & (st["emitter"] < self.n_emitters)
-        reach = np.clip(ev["n_blocks"][st["event"]] - st["j_lo"], 0, P)
-        want = np.where(ev["reserved"][st["event"]] == 1, np.where(st["n_j"] > 0, reach, 0), P).astype(np.int32)
-        need = np.zeros(self.n_emitters, dtype=np.int32)
-        np.maximum.at(need, st["emitter"][real], want[real])
-        unused = np.ones(self.n_emitters, dtype=bool)
-        unused[st["emitter"][real]] = False
-        need[unused] = P
-        return need if (need < P).any() else None
+        column shared by several streams keeps the largest demand.  (csrc/al_plan.cpp: al_plan_emitter_parts.)"""
+        return self._parts(False)
 
     def fused_moving_parts(self, base: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
         """al_batch.emitter_parts for AL_FLAG_FUSED_MOVING: 0 ("energy only": the forward kernel takes the IR's energy for
         normalize_irs and neither transforms nor stores it) for every IR column heard ONLY by sliding-window moving events
-        (al_event.reserved == 1) -- k_moving_fused transforms those partitions itself -- and ``base`` (default: all P
-        partitions) for the others.  None when the batch has no such event."""
-        if not len(self.events) or not len(self.streams) or not (self.events["reserved"] == 1).any() or self.n_partitions < 1:
+        (al_event.reserved == 1) -- k_moving_fused transforms those partitions itself -- and the trimmed count (``base``:
+        None = no trimming, all P partitions) for the others.  None when the batch has no such event."""
+        if not len(self.events) or not (self.events["reserved"] == 1).any() or self.n_partitions < 1:
             return None
-        st, ev = self.streams, self.events
-        real = (ev["n_streams"][st["event"]] > 0) & (st["emitter"] >= 0) & (st["emitter"] < self.n_emitters)
-        out = np.full(self.n_emitters, self.n_partitions, dtype=np.int32) if base is None else np.array(base, dtype=np.int32)
-        fused = np.zeros(self.n_emitters, dtype=bool)
-        other = np.zeros(self.n_emitters, dtype=bool)
-        sliding = ev["reserved"][st["event"]] == 1
-        fused[st["emitter"][real & sliding]] = True
-        other[st["emitter"][real & ~sliding]] = True
-        out[fused & ~other] = 0
+        out = self._parts(True)
+        if out is None:
+            return None
+        if base is None:     # the caller switched the trimming off: full partition counts for the columns that are transformed
+            out = np.where(out == 0, 0, self.n_partitions).astype(np.int32)
         return out
 
     def max_nj_sliding(self) -> int:
@@ -177,6 +209,7 @@ class BatchPlan:
         return out
 
     def workspace_bytes(self) -> int:
+        """Bytes of the spectra workspaces + statistics of the batch as one chunk (al_workspace_bytes)."""
         b8 = self.block * 8
         return (self.hspec_blocks + self.xspec_blocks + self.yspec_blocks) * b8 + self.hspec_blocks * 4 \
             + self.n_emitters * 4 + self.n_partials * 16
@@ -184,94 +217,49 @@ class BatchPlan:
 
 def choose_log2_block(ir_len: int, max_clip: int) -> int:
     """Largest block that keeps two workgroups resident per CU (B = 8192: 68 KiB of LDS each),
-    shrunk for short inputs so the zero padding of the last block stays small."""
-    want = max(min(ir_len, max_clip), 1)
-    lg = 13
-    while lg > MIN_LOG2_BLOCK and (1 << lg) > 2 * want:
-        lg -= 1
-    return lg
+    shrunk for short inputs so the zero padding of the last block stays small (al_choose_log2_block)."""
+    return int(_lib().call("al_choose_log2_block", int(ir_len), int(max_clip)))
+
+
+def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size):
+    arr = (_hip.AlEventSpec * max(len(specs), 1))()
+    for i, sp in enumerate(specs):
+        arr[i] = _hip.AlEventSpec(n_samples=int(sp.n_samples), n_emitters=int(sp.n_emitters), emitter0=int(sp.emitter0),
+                                  is_moving=1 if sp.is_moving else 0, snr=float(sp.snr), ref_db=float(sp.ref_db), gain=float(sp.gain),
+                                  stft_len=int(sp.stft_len or 0), duration=float(sp.duration if sp.duration is not None else 0.0))
+    handle = ct.c_void_p()
+    try:
+        _lib().call("al_plan_create", arr, len(specs), int(n_capsules), int(ir_len), float(sample_rate), int(log2_block or 0), int(hop),
+                    int(win), int(fft_size), ct.byref(handle))
+    except _hip.HipError as exc:       # the reference's ValueErrors, with its messages (synthesize.py:565-584)
+        raise ValueError(str(exc).split("): ", 1)[-1]) from None
+    return handle
 
 
 def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_rate: float,
                log2_block: Optional[int] = None, hop: int = config.HOP_SIZE, win: int = config.WIN_SIZE,
                fft_size: int = config.FFT_SIZE) -> BatchPlan:
-    """Build the kernel tables for a list of events sharing one IR tensor (one microphone)."""
+    """Build the kernel tables for a list of events sharing one IR tensor (one microphone): al_plan_create."""
     if win != 2 * hop or fft_size < 2 * win - 1:
         raise ValueError("the HIP time-variant path needs win_size == 2*hop_size (sin^2 COLA) and fft_size >= 2*win_size-1")
-    if log2_block is None:
-        log2_block = choose_log2_block(ir_len, max([s.n_samples for s in specs], default=1))
-    if not MIN_LOG2_BLOCK <= log2_block <= MAX_LOG2_BLOCK:
+    if log2_block is not None and not MIN_LOG2_BLOCK <= log2_block <= MAX_LOG2_BLOCK:
         raise ValueError(f"log2_block must be in [{MIN_LOG2_BLOCK}, {MAX_LOG2_BLOCK}]")
-    B = 1 << log2_block
-    events = np.zeros(len(specs), dtype=EVENT_DTYPE)
-    streams: List[tuple] = []
-    wcols: List[np.ndarray] = []
-    w_floats = 0
-    audio_off = out_off = 0
-    x_blocks = y_blocks = parts = 0
-    n_emit_used = 0
-    audio_offsets = np.zeros(len(specs), dtype=np.int64)
-    for i, sp in enumerate(specs):
-        La = int(sp.n_samples)
-        if La <= 0:
-            raise ValueError("event clip must have at least one sample")
-        K = -(-La // B)
-        ev = events[i]
-        audio_offsets[i] = audio_off
-        ev["audio_off"], ev["out_off"], ev["len"], ev["n_blocks"] = audio_off, out_off, La, K
-        ev["snr"], ev["ref_db"] = sp.snr, sp.ref_db
-        ev["stream0"], ev["yspec_base"], ev["part_base"] = len(streams), y_blocks, parts
-        valid = La
-        if sp.n_emitters == 0:
-            ev["n_streams"] = 0
-            streams.append((i, 0, 0, 0, 0, -1, 0, sp.gain))  # carries the gain only
-        elif sp.n_emitters == 1:
-            if sp.is_moving:
-                raise ValueError("Moving Event has only one emitter!")
-            ev["n_streams"] = 1
-            streams.append((i, sp.emitter0, 0, K, x_blocks, -1, 0, sp.gain))
-            x_blocks += K
-        else:
-            if not sp.is_moving:
-                raise ValueError("Expected a moving event!")
-            if sp.duration is None:
-                raise ValueError("moving events need Event.duration")
-            w = generate_interpolation_matrix(np.linspace(0, sp.duration, sp.n_emitters), sample_rate, hop)
-            n_frames = min(stft_frame_count(sp.stft_len or La, hop), w.shape[0])
-            valid = min(La, max(n_frames * hop - win, 0))
-            ev["n_streams"] = sp.n_emitters
-            first_stream = len(streams)
-            for l in range(sp.n_emitters):
-                col = w[:n_frames, l]
-                nz = np.flatnonzero(col)
-                if len(nz) == 0:
-                    j_lo, n_j = 0, 0
-                else:
-                    t_lo = max(hop * (int(nz[0]) - 1), 0)
-                    t_hi = min(hop * (int(nz[-1]) + 1), La)
-                    j_lo = t_lo // B
-                    j_hi = min(K - 1, -(-t_hi // B))
-                    n_j = max(j_hi - j_lo + 1, 0) if t_hi > t_lo else 0
-                streams.append((i, sp.emitter0 + l, j_lo, n_j, x_blocks, w_floats, n_frames, sp.gain * fft_size))
-                x_blocks += n_j
-                wcols.append(col.astype(np.float32))
-                w_floats += n_frames
-            mine = streams[first_stream:]
-            starts_ok = all(a[2] <= b_[2] for a, b_ in zip(mine, mine[1:]) if a[3] > 0 and b_[3] > 0)
-            if starts_ok and max(st_[3] for st_ in mine) <= SPARSE_MAX_NJ:
-                ev["reserved"] = 1  # sliding-window accumulate (k_spectral_mac_moving)
-        ev["valid_len"] = valid
-        n_emit_used = max(n_emit_used, sp.emitter0 + sp.n_emitters)
-        y_blocks += n_capsules * K if sp.n_emitters else 0
-        parts += n_capsules * K
-        audio_off += _round_up(La, 4)
-        out_off += _round_up(n_capsules * La, 4)
-    st = np.array(streams, dtype=STREAM_DTYPE) if streams else np.zeros(0, dtype=STREAM_DTYPE)
-    wtab = np.concatenate(wcols) if wcols else np.zeros(1, dtype=np.float32)
-    return BatchPlan(log2_block=log2_block, n_capsules=n_capsules, ir_len=ir_len, n_emitters=n_emit_used,
-                     events=events, streams=st, wtab=wtab, audio_offsets=audio_offsets, audio_floats=max(audio_off, 4),
-                     spatial_floats=max(out_off, 4), xspec_blocks=max(x_blocks, 1), yspec_blocks=max(y_blocks, 1),
-                     n_partials=max(parts, 1), hop=hop, fft_size=fft_size)
+    specs = list(specs)
+    lib = _lib()
+    handle = _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size)
+    try:
+        info = _hip.AlPlanInfo()
+        lib.call("al_plan_get_info", handle, ct.byref(info))
+        events = _copy(lib.call("al_plan_events", handle), info.n_events, EVENT_DTYPE)
+        streams = _copy(lib.call("al_plan_streams", handle), info.n_streams, STREAM_DTYPE)
+        wtab = _copy(lib.call("al_plan_wtab", handle), info.wtab_floats, np.float32)
+        offsets = _copy(lib.call("al_plan_audio_offsets", handle), info.n_events, np.int64)
+    finally:
+        lib.call("al_plan_destroy", handle)
+    return BatchPlan(log2_block=info.log2_block, n_capsules=n_capsules, ir_len=ir_len, n_emitters=info.n_emitters,
+                     events=events, streams=streams, wtab=wtab, audio_offsets=offsets, audio_floats=int(info.audio_floats),
+                     spatial_floats=int(info.spatial_floats), xspec_blocks=int(info.xspec_blocks), yspec_blocks=int(info.yspec_blocks),
+                     n_partials=int(info.n_partials), hop=hop, fft_size=fft_size, _specs=specs, _sample_rate=float(sample_rate), _win=win)
 
 
 # ----------------------------------------------------------------------------- mixdown
@@ -303,30 +291,27 @@ def event_slot(scene_start: float, scene_end: float, sample_rate: float, n_scene
 def plan_mixdown(starts: Sequence[float], ends: Sequence[float], lens: Sequence[int], rows: Sequence[int],
                  src_offsets: Sequence[int], event_index: Sequence[int], duration: float, sample_rate: float,
                  n_capsules: int, tile: int = 4096) -> MixPlan:
-    """Slots and per-tile event lists (events keep insertion order inside every tile)."""
-    n_scene = round(duration * sample_rate)
-    keep, skipped = [], []
-    s_start, s_count = [], []
-    for i, (t0, t1, la) in enumerate(zip(starts, ends, lens)):
-        a, b = event_slot(t0, t1, sample_rate, n_scene)
-        if b <= a:
-            skipped.append(i)
-            continue
-        keep.append(i)
-        s_start.append(a)
-        s_count.append(min(b - a, int(la)))
-    n_tiles = -(-n_scene // tile)
-    lists: List[List[int]] = [[] for _ in range(n_tiles)]
-    for slot, (a, cnt) in enumerate(zip(s_start, s_count)):
-        for t in range(a // tile, min((a + cnt - 1) // tile, n_tiles - 1) + 1):
-            lists[t].append(slot)
-    ptr = np.zeros(n_tiles + 1, dtype=np.int32)
-    ptr[1:] = np.cumsum([len(x) for x in lists])
-    flat = np.array([s for x in lists for s in x], dtype=np.int32) if ptr[-1] else np.zeros(1, dtype=np.int32)
-    sel = np.array(keep, dtype=int)
-    as_i32 = lambda seq: np.asarray(seq, dtype=np.int32)[sel] if len(sel) else np.zeros(1, dtype=np.int32)
-    return MixPlan(n_capsules=n_capsules, n_samples=n_scene, tile=tile, tile_ptr=ptr, tile_events=flat,
-                   slot_src=(np.asarray(src_offsets, dtype=np.int64)[sel] if len(sel) else np.zeros(1, dtype=np.int64)),
-                   slot_len=as_i32(lens), slot_start=np.array(s_start or [0], dtype=np.int32),
-                   slot_count=np.array(s_count or [0], dtype=np.int32), slot_rows=as_i32(rows),
-                   slot_event=as_i32(event_index), skipped=skipped)
+    """Slots and per-tile event lists (events keep insertion order inside every tile): al_plan_mixdown."""
+    n = len(starts)
+    a = np.ascontiguousarray(starts, dtype=np.float64)
+    b = np.ascontiguousarray(ends, dtype=np.float64)
+    la = np.ascontiguousarray(lens, dtype=np.int32)
+    rw = np.ascontiguousarray(rows, dtype=np.int32)
+    so = np.ascontiguousarray(src_offsets, dtype=np.int64)
+    ei = np.ascontiguousarray(event_index, dtype=np.int32)
+    lib = _lib()
+    handle = ct.c_void_p()
+    lib.call("al_plan_mixdown", a.ctypes.data, b.ctypes.data, la.ctypes.data, rw.ctypes.data, so.ctypes.data, ei.ctypes.data, n,
+             float(duration), float(sample_rate), int(n_capsules), int(tile), ct.byref(handle))
+    try:
+        t = _hip.AlMixTables()
+        lib.call("al_mix_plan_get", handle, ct.byref(t))
+        ns = max(t.n_slots, 1)
+        return MixPlan(n_capsules=t.n_capsules, n_samples=t.n_samples, tile=t.tile,
+                       tile_ptr=_copy(t.tile_ptr, t.n_tiles + 1, np.int32), tile_events=_copy(t.tile_events, max(t.n_tile_events, 1), np.int32),
+                       slot_src=_copy(t.slot_src, ns, np.int64), slot_len=_copy(t.slot_len, ns, np.int32),
+                       slot_start=_copy(t.slot_start, ns, np.int32), slot_count=_copy(t.slot_count, ns, np.int32),
+                       slot_rows=_copy(t.slot_rows, ns, np.int32), slot_event=_copy(t.slot_event, ns, np.int32),
+                       skipped=[int(x) for x in _copy(t.skipped, t.n_skipped, np.int32)])
+    finally:
+        lib.call("al_mix_plan_destroy", handle)

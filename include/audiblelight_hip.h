@@ -28,8 +28,9 @@ extern "C" {
  * with; a host must compare it with the AL_ABI_VERSION it was compiled against before passing any struct (al_batch and
  * al_mix grew fields in version 2: clip_scale, xspec/hspec_zero_block, ambience, ambience_scale; version 3 puts
  * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread;
- * version 4 appends al_batch.emitter_parts). */
-#define AL_ABI_VERSION 4
+ * version 4 appends al_batch.emitter_parts; version 5 adds the host-side planner (al_plan_*, al_workspace_bytes,
+ * al_plan_mixdown) and the AL_FLAG_QUAD_SPECTRA / AL_FLAG_FUSED_MOVING path: no struct changed). */
+#define AL_ABI_VERSION 5
 
 #define AL_OK 0
 #define AL_E_BADARG (-1)
@@ -360,6 +361,71 @@ int al_resample_poly(const float *x, int32_t rows, int64_t n_in, const float *ta
 #define AL_FRAMES_F32 0
 #define AL_FRAMES_PCM16 1
 int al_encode_frames(const float *scene, int32_t n_capsules, int64_t n_samples, int32_t format, void *out, al_stream_t stream);
+
+/* ---- Planning (host side, no device call; csrc/al_plan.cpp).  Everything al_batch / al_mix point to is index arithmetic on
+ * shapes: which signal blocks a moving event's cross-fade windows touch (generate_interpolation_matrix, synthesize.py:148-181),
+ * where every event's spectra, statistics and audio live, which events overlap which mixdown tile (event slots with Python's
+ * round-half-even, synthesize.py:361-362).  A host builds the tables here, copies them to the device and fills al_batch / al_mix
+ * with the device pointers.  The plan owns its arrays; the accessors return HOST pointers valid until al_plan_destroy. */
+typedef struct {
+  int32_t n_samples;   /* clip length La */
+  int32_t n_emitters;  /* len(event): 0 = clip tiled over the capsules, 1 = static, > 1 = moving (synthesize.py:564-587) */
+  int32_t emitter0;    /* first IR column of this event (synthesize.py:662) */
+  int32_t is_moving;
+  float snr;           /* Event.snr */
+  float ref_db;        /* Scene.ref_db */
+  float gain;          /* scalar folded into the clip (peak normalisation, FX gain / polarity); 1 = none */
+  int32_t stft_len;    /* samples the STFT frame count is taken from; 0 = n_samples */
+  double duration;     /* Event.duration in seconds (moving events) */
+} al_event_spec;
+
+typedef struct {
+  int32_t log2_block, n_capsules, ir_len, n_events, n_streams, n_emitters, n_partitions, hop, fft_size;
+  int32_t max_blocks;       /* al_batch.max_blocks of the whole batch */
+  int32_t max_nj;           /* al_batch.max_nj */
+  int32_t max_nj_sliding;   /* longest stream of the sliding-window events (<= 5: AL_FLAG_FUSED_NJ5 may be set) */
+  int32_t xspec_blocks, yspec_blocks, n_partials;   /* blocks of B complex / entries of 4 floats */
+  int32_t reserved;
+  int64_t hspec_blocks;     /* n_emitters * n_capsules * n_partitions */
+  int64_t audio_floats, spatial_floats, wtab_floats;
+} al_plan_info;
+
+typedef struct al_plan al_plan;
+typedef struct al_mix_plan al_mix_plan;
+
+typedef struct {            /* what al_mix needs, as host arrays owned by the al_mix_plan */
+  int32_t n_capsules, n_samples, tile, n_tiles, n_slots, n_tile_events, n_skipped, reserved;
+  const int32_t *tile_ptr;     /* n_tiles + 1 */
+  const int32_t *tile_events;  /* max(n_tile_events, 1) */
+  const int64_t *slot_src;     /* max(n_slots, 1) entries each, as al_mix documents them */
+  const int32_t *slot_len, *slot_start, *slot_count, *slot_rows, *slot_event;
+  const int32_t *skipped;      /* n_skipped: events whose slot is empty after rounding (synthesize.py:364-370 warns and skips) */
+} al_mix_tables;
+
+const char *al_plan_last_error(void);
+int32_t al_choose_log2_block(int32_t ir_len, int32_t max_clip);
+int32_t al_stft_frame_count(int64_t n_samples, int32_t hop);                          /* synthesize.py:123 */
+int32_t al_interpolation_rows(int32_t n_irs, double duration, double sample_rate, int32_t hop);
+/* generate_interpolation_matrix (synthesize.py:148-181) for ir_times = linspace(0, duration, n_irs): rows x n_irs float64 */
+int al_interpolation_matrix(int32_t n_irs, double duration, double sample_rate, int32_t hop, int32_t rows, double *weights);
+/* log2_block <= 0: chosen from the lengths.  Errors carry the reference's messages ("Moving Event has only one emitter!", ...). */
+int al_plan_create(const al_event_spec *specs, int32_t n_events, int32_t n_capsules, int32_t ir_len, double sample_rate,
+                   int32_t log2_block, int32_t hop, int32_t win, int32_t fft_size, al_plan **out);
+void al_plan_destroy(al_plan *plan);
+int al_plan_get_info(const al_plan *plan, al_plan_info *info);
+const al_event *al_plan_events(const al_plan *plan);          /* n_events */
+const al_stream *al_plan_streams(const al_plan *plan);        /* n_streams */
+const float *al_plan_wtab(const al_plan *plan);               /* wtab_floats */
+const int64_t *al_plan_audio_offsets(const al_plan *plan);    /* n_events: where each clip goes inside `audio` */
+/* bytes of the spectra workspaces + statistics of the whole batch as ONE chunk (hspec, xspec, yspec, ir_energy, emitter_gain, partials) */
+int64_t al_workspace_bytes(const al_plan *plan);
+/* al_batch.emitter_parts: returns 1 and fills out[n_emitters] if the batch needs the table, 0 if every IR needs all partitions */
+int al_plan_emitter_parts(const al_plan *plan, int32_t fused_moving, int32_t *out);
+int al_plan_mixdown(const double *starts, const double *ends, const int32_t *lens, const int32_t *rows, const int64_t *src_offsets,
+                    const int32_t *event_index, int32_t n, double duration, double sample_rate, int32_t n_capsules, int32_t tile,
+                    al_mix_plan **out);
+void al_mix_plan_destroy(al_mix_plan *plan);
+int al_mix_plan_get(const al_mix_plan *plan, al_mix_tables *tables);
 
 /* dst[t] = src[t mod m] for t < n: np.pad(..., mode="wrap") of Augmentation.process. */
 int al_wrap_copy(const float *src, int64_t m, float *dst, int64_t n, al_stream_t stream);

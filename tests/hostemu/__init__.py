@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 LIB = os.path.join(HERE, "_build", "libal_hostemu.so")
 CSRC = os.path.join(ROOT, "audiblelight_amd", "csrc")
-SRCS = [os.path.join(CSRC, "al_kernels.hip"), os.path.join(CSRC, "al_transforms.hip")]
+SRCS = [os.path.join(CSRC, "al_kernels.hip"), os.path.join(CSRC, "al_transforms.hip"), os.path.join(CSRC, "al_plan.cpp")]
 
 
 def build(sanitize: bool = False) -> str:

@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "audiblelight_hip.h")).read()
     declared = set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
-    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 4
+    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 5
     assert lib.call("al_twiddle_bytes", 13) == 8 * 8192 and lib.call("al_twiddle_bytes", 9) == -1
     assert lib.call("al_row_stats_partials", 3, 40000) == 4 * 3 * 3
     assert lib.call("al_noise_workspace_floats", 2, 1000) > 0
@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header():
     assert ct.sizeof(_hip.AlBatch) == 2 * 4 + 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4 + 8   # head, ..., 16 pointers, the two zero-block indices, emitter_parts
     assert ct.sizeof(_hip.AlMix) == 2 * 4 + 6 * 4 + 13 * 8
     b, m = _hip.AlBatch(log2_block=13), _hip.AlMix()
-    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (232, 4, 136, 4)
+    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (232, 5, 136, 5)
     assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
 
 
@@ -317,3 +317,89 @@ def test_every_accumulate_instantiation_is_named_by_a_gpu_test():
     # and the other way round: every asserted code has a kernel behind it
     have = {c for sym in syms for c in mr.codes_of_kernel_symbol(sym)}
     assert asserted <= have, sorted(asserted - have)
+
+
+# ----------------------------------------------------------------------------- the planner behind the C ABI (csrc/al_plan.cpp)
+def _random_specs(rng, sr):
+    specs, col = [], 0
+    for _ in range(int(rng.integers(1, 6))):
+        kind = rng.choice(["static", "static", "moving", "dry"])
+        n = int(rng.integers(600, 200000)) if kind == "moving" else int(rng.integers(1, 200000))
+        ne = {"static": 1, "dry": 0, "moving": int(rng.integers(2, 40))}[kind]
+        specs.append(dict(n_samples=n, n_emitters=ne, snr=float(rng.uniform(5, 30)), emitter0=col, is_moving=ne > 1, duration=n / sr,
+                          gain=float(rng.uniform(0.1, 2)), ref_db=float(rng.uniform(-70, -40))))
+        col += ne
+    return specs
+
+
+def _same_optional(a, b):
+    return (a is None and b is None) or (a is not None and b is not None and np.array_equal(a, b))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_c_planner_tables_equal_the_numpy_planner(seed):
+    """al_plan_create / al_plan_emitter_parts / al_workspace_bytes (what audiblelight_amd/plan.py calls) against the numpy
+    planner of rounds 1-3 (tests/plan_reference.py): every table bit for bit on random batches of static, moving and tiled
+    events, every block size, with and without the fused-moving emitter table."""
+    from tests import plan_reference as ref
+
+    rng = np.random.default_rng(900 + seed)
+    for _ in range(40):
+        sr = float(rng.choice([8000, 16000, 44100, 48000]))
+        C, L = int(rng.integers(1, 9)), int(rng.integers(1, 40000))
+        lb = rng.choice([0, 10, 11, 12, 13, 14])
+        lb = None if lb == 0 else int(lb)
+        specs = _random_specs(rng, sr)
+        a = planning.plan_batch([planning.EventSpec(**k) for k in specs], C, L, sr, log2_block=lb)
+        b = ref.plan_batch([ref.EventSpec(**k) for k in specs], C, L, sr, log2_block=lb)
+        assert a.log2_block == b.log2_block and a.events.tobytes() == b.events.tobytes() and a.streams.tobytes() == b.streams.tobytes()
+        assert np.array_equal(a.wtab, b.wtab) and np.array_equal(a.audio_offsets, b.audio_offsets)
+        assert (a.audio_floats, a.spatial_floats, a.xspec_blocks, a.yspec_blocks, a.n_partials, a.n_emitters) == \
+               (b.audio_floats, b.spatial_floats, b.xspec_blocks, b.yspec_blocks, b.n_partials, b.n_emitters)
+        pa, pb = a.emitter_parts(), b.emitter_parts()
+        assert _same_optional(pa, pb)
+        assert _same_optional(a.fused_moving_parts(pa), b.fused_moving_parts(pb))
+        assert a.workspace_bytes() == b.workspace_bytes() and a.max_nj_sliding() == b.max_nj_sliding()
+        handle = a._c_plan()
+        try:
+            assert _hip.get_library().call("al_workspace_bytes", handle) == b.workspace_bytes()
+        finally:
+            _hip.get_library().call("al_plan_destroy", handle)
+
+
+def test_c_planner_mixdown_and_weights_equal_the_numpy_planner():
+    from tests import plan_reference as ref
+
+    rng = np.random.default_rng(77)
+    for _ in range(200):
+        sr = float(rng.choice([8000, 22050, 48000]))
+        dur = float(rng.uniform(0.2, 20.0))
+        n = int(rng.integers(0, 9))
+        starts = rng.uniform(-1.0, dur, n)
+        lens = rng.integers(1, 200000, n).astype(np.int32)
+        ends = starts + lens / sr + rng.uniform(-0.5, 0.5, n)
+        # half-sample starts exercise Python's round-half-even (synthesize.py:361-362)
+        if n:
+            starts[0] = (int(starts[0] * sr) + 0.5) / sr
+        rows = rng.integers(1, 5, n).astype(np.int32)
+        src = np.cumsum(rng.integers(4, 1000, n)).astype(np.int64)
+        a = planning.plan_mixdown(starts, ends, lens, rows, src, list(range(n)), dur, sr, 4)
+        b = ref.plan_mixdown(starts, ends, lens, rows, src, list(range(n)), dur, sr, 4)
+        for f in ("tile_ptr", "tile_events", "slot_src", "slot_len", "slot_start", "slot_count", "slot_rows", "slot_event"):
+            assert np.array_equal(getattr(a, f), getattr(b, f)), f
+        assert (a.n_samples, a.n_tiles, a.skipped) == (b.n_samples, b.n_tiles, b.skipped)
+    for n_ir, dur, sr in ((3, 0.75, 8000), (5, 1.125, 8000), (32, 7.75, 48000), (2, 0.1, 44100), (17, 3.3333, 22050), (1, 1.0, 8000)):
+        t = np.linspace(0, dur, n_ir)
+        np.testing.assert_array_equal(planning.generate_interpolation_matrix(t, sr, 128), ref.generate_interpolation_matrix(t, sr, 128))
+        np.testing.assert_array_equal(planning.generate_interpolation_matrix(t, sr, 128), orc.crossfade_weights(t, sr, 128))
+
+
+def test_c_planner_refuses_what_the_reference_refuses():
+    with pytest.raises(ValueError, match="Moving Event has only one emitter!"):
+        planning.plan_batch([planning.EventSpec(10, 1, 1.0, is_moving=True)], 1, 10, 8000)
+    with pytest.raises(ValueError, match="Expected a moving event!"):
+        planning.plan_batch([planning.EventSpec(10, 2, 1.0)], 1, 10, 8000)
+    with pytest.raises(ValueError, match="at least one sample"):
+        planning.plan_batch([planning.EventSpec(0, 1, 1.0)], 1, 10, 8000)
+    with pytest.raises(ValueError, match="moving events need Event.duration"):
+        planning.plan_batch([planning.EventSpec(9000, 3, 1.0, is_moving=True)], 1, 10, 8000)

@@ -96,6 +96,11 @@ class AlMixTables(ct.Structure):      # al_mix_tables
                                            "slot_event", "skipped")]
 
 
+class AlChunk(ct.Structure):          # al_chunk
+    _fields_ = [(n, ct.c_int32) for n in ("event0", "n_events", "stream0", "n_streams", "emitter0", "n_emitters", "xspec_block0",
+                                          "xspec_blocks", "yspec_block0", "yspec_blocks", "max_blocks", "max_nj")]
+
+
 class HipError(RuntimeError):
     """A C-ABI call returned a negative status."""
 
@@ -131,6 +136,7 @@ SYMBOLS = {
     "al_plan_wtab": (ct.c_void_p, [_P]),
     "al_plan_audio_offsets": (ct.c_void_p, [_P]),
     "al_workspace_bytes": (ct.c_int64, [_P]),
+    "al_plan_chunk": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.POINTER(AlChunk)]),
     "al_plan_emitter_parts": (ct.c_int, [_P, ct.c_int32, _P]),
     "al_plan_mixdown": (ct.c_int, [_P, _P, _P, _P, _P, _P, ct.c_int32, ct.c_double, ct.c_double, ct.c_int32, ct.c_int32,
                                    ct.POINTER(ct.c_void_p)]),

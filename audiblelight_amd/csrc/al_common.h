@@ -102,6 +102,21 @@ struct SpectraView {
 };
 constexpr int SPECTRA_POISON = (int)0x80000000u;
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: hipcc puts s_waitcnt vmcnt(0) in
+// front of its s_barrier, which drains every global load in flight -- a kernel that requests data a phase ahead of its use
+// (k_moving_fused: the next round's samples during this round's products) would wait for it at the very next barrier.  Here only
+// the LDS counter is waited on; registers loaded from global memory are still guarded by the waits hipcc inserts at their use.
+template <bool LDS_ONLY>
+__device__ __forceinline__ void block_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (LDS_ONLY) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    return;
+  }
+#endif
+  __syncthreads();
+}
+
 __device__ __forceinline__ void pipeline_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
   __builtin_amdgcn_sched_barrier(0);

@@ -336,7 +336,7 @@ struct PackFactors {
 //   butterfly j = tid + T*b reads in[j + r*M/R]      = v[b + r*NB]
 //   k = j mod NS;  factor exp(DIR*2*pi*i*r*k/(NS*R))
 //   out[(j - k)*R + k + q*NS] = X[q]
-template <class G, int DIR, int PASS, bool TO_REGS = false>
+template <class G, int DIR, int PASS, bool TO_REGS = false, bool LDS_ONLY = false>
 __device__ __forceinline__ void fft_pass(float2 (&v)[G::E], float2 *s, const PassTwiddles<G, PASS> &t, int tid) {
   constexpr int E = G::E, T = G::T;
   constexpr int R = G::radix(PASS), NS = G::ns(PASS), NB = E / R;
@@ -353,7 +353,7 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[G::E], float2 *s, const Pas
       for (int r = 1; r < R; ++r) v[b + r * NB] = cmul(v[b + r * NB], w[r]);
     }
     // all LDS reads of this pass are done once every thread is here
-    __syncthreads();
+    block_barrier<LDS_ONLY>();
   }
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -379,21 +379,21 @@ __device__ __forceinline__ void fft_pass(float2 (&v)[G::E], float2 *s, const Pas
 #pragma unroll
     for (int q = 0; q < R; ++q) wr[q * QS] = v[b + q * NB];
   }
-  __syncthreads();
+  block_barrier<LDS_ONLY>();
 }
 
-template <class G, int DIR, int PASS, bool LAST_REGS>
+template <class G, int DIR, int PASS, bool LAST_REGS, bool LDS_ONLY = false>
 struct FftPasses {
   static __device__ __forceinline__ void run(float2 (&v)[G::E], float2 *s, const FftTwiddles<G> &t, int tid) {
     if constexpr (PASS == 0) {
       PassTwiddles<G, 0> none;  // pass 0 has unit twiddles
-      fft_pass<G, DIR, 0>(v, s, none, tid);
-      FftPasses<G, DIR, 1, LAST_REGS>::run(v, s, t, tid);
+      fft_pass<G, DIR, 0, false, LDS_ONLY>(v, s, none, tid);
+      FftPasses<G, DIR, 1, LAST_REGS, LDS_ONLY>::run(v, s, t, tid);
     } else if constexpr (PASS + 1 < G::NPASSES) {
-      fft_pass<G, DIR, PASS>(v, s, t.template pass<PASS>(), tid);
-      FftPasses<G, DIR, PASS + 1, LAST_REGS>::run(v, s, t, tid);
+      fft_pass<G, DIR, PASS, false, LDS_ONLY>(v, s, t.template pass<PASS>(), tid);
+      FftPasses<G, DIR, PASS + 1, LAST_REGS, LDS_ONLY>::run(v, s, t, tid);
     } else {
-      fft_pass<G, DIR, PASS, LAST_REGS>(v, s, t.template pass<PASS>(), tid);
+      fft_pass<G, DIR, PASS, LAST_REGS, LDS_ONLY>(v, s, t.template pass<PASS>(), tid);
     }
   }
 };

@@ -221,6 +221,38 @@ int64_t al_workspace_bytes(const al_plan *p) {
   return (h + p->xspec_blocks + p->yspec_blocks) * b8 + h * 4 + (int64_t)p->n_emitters * 4 + (int64_t)p->n_partials * 16;
 }
 
+// The al_batch fields of a run of consecutive events ("chunk") over the plan's global tables: a long scene is rendered as several
+// chunks that reuse ONE spectra workspace (al_batch.event0 / stream0 / emitter0 / *_block0).
+int al_plan_chunk(const al_plan *p, int32_t event0, int32_t n_events, al_chunk *out) {
+  if (!p || !out || event0 < 0 || n_events < 0 || event0 + n_events > (int32_t)p->events.size()) return plan_fail(AL_E_BADARG, "bad chunk range");
+  memset(out, 0, sizeof(*out));
+  out->event0 = event0; out->n_events = n_events;
+  if (n_events == 0) return AL_OK;
+  const al_event &e_first = p->events[event0], &e_last = p->events[event0 + n_events - 1];
+  const int32_t s0 = e_first.stream0, s1 = e_last.stream0 + std::max(e_last.n_streams, 1);
+  out->stream0 = s0; out->n_streams = s1 - s0;
+  int64_t em0 = INT64_MAX, em1 = 0, x0 = INT64_MAX, x1 = 0, y0 = INT64_MAX, y1 = 0;
+  for (int32_t i = event0; i < event0 + n_events; ++i) {
+    const al_event &e = p->events[i];
+    out->max_blocks = std::max(out->max_blocks, e.n_blocks);
+    if (e.n_streams > 0) {
+      y0 = std::min<int64_t>(y0, e.yspec_base);
+      y1 = std::max<int64_t>(y1, (int64_t)e.yspec_base + (int64_t)p->n_capsules * e.n_blocks);
+      for (int32_t s = e.stream0; s < e.stream0 + e.n_streams; ++s) {   // streams of convolved events (pseudo-streams of tiled events carry no spectra)
+        const al_stream &st = p->streams[s];
+        em0 = std::min<int64_t>(em0, st.emitter); em1 = std::max<int64_t>(em1, (int64_t)st.emitter + 1);
+        x0 = std::min<int64_t>(x0, st.xspec_base); x1 = std::max<int64_t>(x1, (int64_t)st.xspec_base + st.n_j);
+      }
+    }
+  }
+  for (int32_t s = s0; s < s1; ++s) out->max_nj = std::max(out->max_nj, p->streams[s].n_j);
+  const bool conv = em1 > 0 || x1 > 0 || y1 > 0;
+  out->emitter0 = conv && em0 != INT64_MAX ? (int32_t)em0 : 0; out->n_emitters = conv && em0 != INT64_MAX ? (int32_t)(em1 - em0) : 0;
+  out->xspec_block0 = x0 != INT64_MAX ? (int32_t)x0 : 0; out->xspec_blocks = x0 != INT64_MAX ? (int32_t)(x1 - x0) : 0;
+  out->yspec_block0 = y0 != INT64_MAX ? (int32_t)y0 : 0; out->yspec_blocks = y0 != INT64_MAX ? (int32_t)(y1 - y0) : 0;
+  return AL_OK;
+}
+
 // al_batch.emitter_parts for the whole plan.  Returns 1 and fills out[n_emitters] when the batch needs the table (some IR has
 // partitions no kept block hears, or -- fused_moving != 0 -- some IR column is heard only by sliding-window events and is
 // therefore transformed by k_moving_fused itself: 0 = "energy only"), 0 when every IR needs all its partitions (out untouched).

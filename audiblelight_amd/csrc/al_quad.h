@@ -35,8 +35,8 @@
 #include "al_common.h"
 #include "al_fft.h"
 
-// Timing builds (profiles/tools/build_defs.sh): bit 0 no raw loads (the fold gets lane-made values), bit 1 no transform passes,
-// bit 2 no products, bit 3 no LDS stage traffic, bit 4 no look-ahead (every round requests its own samples).  0 = the product.
+// Timing builds: bit 2 no products, bit 4 no look-ahead (every round requests its own samples).  0 = the product.
+// (The first version's phase timings -- loads, transforms, products, stage: profiles/r04c_moving_fused_phase_timing.txt.)
 #ifndef AL_MF_SKIP
 #define AL_MF_SKIP 0
 #endif
@@ -147,8 +147,8 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
   using G = FftGeom<11, 16>;
   constexpr int Q = 2048, B = 8192, W = NJW + PTW - 1, NG = 4, ROUNDS = PTW / 4;
   static_assert(PTW % 4 == 0 && G::T == 128, "four 128-thread groups transform four partitions per round");
-  __shared__ float2 img[NG][G::LDS_ELEMS];
-  __shared__ float2 stage[NG][Q];
+  __shared__ float2 img[NG][G::LDS_ELEMS];      // transform images; after the last pass: the partition's tile in natural order (padded)
+  __shared__ float4 xlds[NJW * 2][512];          // the stream's signal blocks, each thread's own 4 slots (read back by their writer only)
   __shared__ int4 tab[64];    // {j_lo, n_j, emitter, xspec_base - xspec_block0}
   __shared__ float gains[64];
   const int tid = threadIdx.x, g = tid >> 7, tg0 = tid & 127;
@@ -225,13 +225,16 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
           ++kbase;
         }
         const float gn = gains[l];
-        Quad4 x[NJW];
+        // the stream's signal blocks, times the emitter gain, parked in LDS: live in registers only during the products
+        // (a thread reads back only what it wrote itself: no barrier)
 #pragma unroll
         for (int jj = 0; jj < NJW; ++jj) {
-          x[jj] = load4(X + (int64_t)(t.w + min(jj, nj - 1)) * B);
-          const float sc = jj < nj ? gn : 0.f;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) x[jj].s[i] = make_float2(x[jj].s[i].x * sc, x[jj].s[i].y * sc);
+          if (jj < nj) {                                  // workgroup-uniform
+            const float2 *xp = X + (int64_t)(t.w + jj) * B;
+            const float4 a = *reinterpret_cast<const float4 *>(xp), bq = *reinterpret_cast<const float4 *>(xp + 2);
+            xlds[2 * jj][tid] = make_float4(a.x * gn, a.y * gn, a.z * gn, a.w * gn);
+            xlds[2 * jj + 1][tid] = make_float4(bq.x * gn, bq.y * gn, bq.z * gn, bq.w * gn);
+          }
         }
         const float *irc = b.ir + (int64_t)c * b.ir_stride_c;
         static_for<ROUNDS>([&](auto r_c) {
@@ -252,24 +255,37 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
               else issue_raw<false>(src, remaining, live, tg, raw);
             }
             float2 z[16];
-            if (AL_MF_SKIP & 1) {
-#pragma unroll
-              for (int m = 0; m < 16; ++m) z[m] = make_float2(wb.x * (float)(m + p), wb.y - (float)remaining);
-            } else {
-              switch (tile) {                             // workgroup-uniform
-                case 0: fold_raw<0>(raw, remaining, live, tg, wb, z); break;
-                case 1: fold_raw<1>(raw, remaining, live, tg, wb, z); break;
-                case 2: fold_raw<2>(raw, remaining, live, tg, wb, z); break;
-                default: fold_raw<3>(raw, remaining, live, tg, wb, z); break;
-              }
+            switch (tile) {                               // workgroup-uniform
+              case 0: fold_raw<0>(raw, remaining, live, tg, wb, z); break;
+              case 1: fold_raw<1>(raw, remaining, live, tg, wb, z); break;
+              case 2: fold_raw<2>(raw, remaining, live, tg, wb, z); break;
+              default: fold_raw<3>(raw, remaining, live, tg, wb, z); break;
             }
-            if (!(AL_MF_SKIP & 2)) fft_regs_to_regs<G, -1>(z, img[g], tw, tg);   // z[m] = Z[tg + 128 m]; its last LDS reads end with a barrier
-            if (!(AL_MF_SKIP & 8)) {
-              if (tile == 0 && !(AL_MF_SKIP & 2)) {
-                real_unpack_store_regs<G>(z, img[g], tw.w0, tg, stage[g]);
-              } else {
+            // all passes through LDS: the last one leaves the transform in the image in natural order (slot i at pad(i)) AND in
+            // z[m] = Z[tg + 128 m], and ends with a barrier -- the image IS the stage the products read
+            FftPasses<G, -1, 0, false, true>::run(z, img[g], tw, tg);
+            if (tile == 0) {
+              // real-FFT unpacking of tile 0, in place: thread owning k = tg + 128 m (m < 8) reads Z[M - k] from the image and
+              // writes slots k and M - k; nobody else reads or writes either, so no barrier in between (formulas: al_fft.h)
+              constexpr int M = G::M, T = G::T, H = G::H;
+              constexpr PackFactors<G> pf{};
+              float2 *s_ = img[g];
 #pragma unroll
-                for (int m = 0; m < 16; ++m) stage[g][tg + 128 * m] = z[m];
+              for (int m = 0; m < H; ++m) {
+                const int k = tg + T * m;
+                if (m == 0 && k == 0) {
+                  const float2 z0 = z[0], zh = z[H];
+                  s_[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
+                  s_[G::pad(M / 2)] = cconj(zh);
+                } else {
+                  const float2 wm = m == 0 ? tw.w0 : cmul(tw.w0, make_float2(pf.c[m], -pf.s[m]));
+                  const float2 zk = z[m], zm = s_[G::pad(M - k)];
+                  const float2 e_ = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                  const float2 d_ = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+                  const float2 wo = cmul(wm, make_float2(d_.y, -d_.x));
+                  s_[G::pad(k)] = cadd(e_, wo);
+                  s_[G::pad(M - k)] = cconj(csub(e_, wo));
+                }
               }
             }
             // The NEXT round's samples are requested now and folded a whole accumulate phase later: with one workgroup per CU
@@ -295,17 +311,23 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
                 else issue_raw<false>(src, rem2, np_ < npe, tg2, raw);
               }
             }
-            __syncthreads();
+            if (tile == 0) block_barrier<true>();         // tile 0's unpacking wrote the image after the last pass's barrier
+            Quad4 x[NJW];
+#pragma unroll
+            for (int jj = 0; jj < NJW; ++jj) {
+              if (jj < nj) {
+                const float4 a = xlds[2 * jj][tid], bq = xlds[2 * jj + 1][tid];
+                x[jj].s[0] = make_float2(a.x, a.y); x[jj].s[1] = make_float2(a.z, a.w);
+                x[jj].s[2] = make_float2(bq.x, bq.y); x[jj].s[3] = make_float2(bq.z, bq.w);
+              }
+            }
             static_for<4>([&](auto gg_c) {
               constexpr int gg = decltype(gg_c)::value, pp = 4 * r + gg;
               if (p0 + pp < pe) {                         // workgroup-uniform
-                Quad4 h;
-                if (AL_MF_SKIP & 8) {
-                  const float2 zz = make_float2((float)tid, 1.f);
-                  h.s[0] = h.s[1] = h.s[2] = h.s[3] = zz;
-                } else {
-                  h = load4(&stage[gg][4 * tid]);
-                }
+                Quad4 h;                                  // slots 4 tid .. 4 tid + 3 of partition gg: contiguous inside one padded 16-group
+                const float2 *hp = &img[gg][4 * tid + (tid >> 2)];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) h.s[i] = hp[i];
 #pragma unroll
                 for (int jj = 0; jj < NJW; ++jj) {
                   if ((AL_MF_SKIP & 4) || jj >= nj) continue;   // workgroup-uniform: blocks past the stream's last are not multiplied
@@ -322,7 +344,8 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
                 }
               }
             });
-            // no barrier here: the next write of the stage lies behind the barriers of the next round's transform passes
+            block_barrier<true>();                        // the images are free for the next round's first pass (LDS-only
+                                                          // barriers throughout: the look-ahead loads stay in flight)
           }
         });
       }
@@ -340,16 +363,19 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
   }
 }
 
-// Which instantiation takes a batch: NJW = 5 (cfg3: cross-fade windows of 2.9 blocks) in passes of 8 partitions, NJW = 6 in
-// passes of 4 (the accumulator window is what fills the register file).
-int moving_fused_code(const al_batch *b) { return 10000 + ((b->flags & AL_FLAG_FUSED_NJ5) ? 508 : 604); }
+// One instantiation: streams of at most 5 signal blocks (cfg3: cross-fade windows of 2.9 blocks), passes of 8 partitions.  The
+// LDS budget (four transform images + the stream's signal blocks: 150 KB of 160) is what bounds NJW; longer streams stay
+// on k_spectral_mac_moving over stored spectra.
+#ifndef AL_MF_PTW5
+#define AL_MF_PTW5 8   /* partitions per pass (A/B switch of the timing builds) */
+#endif
+int moving_fused_code(const al_batch *b) { (void)b; return 10000 + 500 + AL_MF_PTW5; }
 
 hipError_t launch_moving_fused(const al_batch *b, hipStream_t stream) {
   const int64_t pairs = (int64_t)b->n_capsules * b->n_events, ids = (pairs + 7) / 8 * 8 * 4;
   if (ids > 0x7fffffff) return hipErrorInvalidValue;
   const dim3 grid((unsigned)ids);
-  if (b->flags & AL_FLAG_FUSED_NJ5) hipLaunchKernelGGL((k_moving_fused<5, 8>), grid, dim3(512), 0, stream, *b);
-  else hipLaunchKernelGGL((k_moving_fused<6, 4>), grid, dim3(512), 0, stream, *b);
+  hipLaunchKernelGGL((k_moving_fused<5, AL_MF_PTW5>), grid, dim3(512), 0, stream, *b);
   return hipGetLastError();
 }
 

@@ -452,6 +452,7 @@ class Renderer:
         fused_static = os.environ.get("AL_FUSED", "0") == "1"
         fuse_moving = (os.environ.get("AL_FUSED_MOVING", "1") == "1" and plan.log2_block == 13 and not fused_static
                        and os.environ.get("AL_SPLIT", "1") == "1" and 1 <= P <= SPARSE_MAX_PARTITIONS)
+        fuse_moving = fuse_moving and 0 < plan.max_nj_sliding() <= 5     # the kernel keeps a stream's blocks in LDS: 5 is what fits
         fused_parts = plan.fused_moving_parts(parts) if fuse_moving else None
         fuse_moving = fused_parts is not None
         if fuse_moving:
@@ -498,7 +499,7 @@ class Renderer:
             for desc in descs:
                 desc.flags |= _hip.FLAG_SPLIT_SPECTRA
                 if fuse_moving:
-                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
+                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | _hip.FLAG_FUSED_NJ5
                 elif plan.log2_block == 13 and os.environ.get("AL_QUAD", "0") == "1":   # A/B + test switch: the quad layout alone
                     desc.flags |= _hip.FLAG_QUAD_SPECTRA
         # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes

@@ -179,33 +179,20 @@ class BatchPlan:
 
     def chunks(self, chunk_events: Optional[int] = None) -> List[dict]:
         """Split the batch into runs of ``chunk_events`` consecutive events that share the global
-        tables (al_batch.event0 / stream0 / emitter0 / *_block0, include/audiblelight_hip.h)."""
+        tables (al_batch.event0 / stream0 / emitter0 / *_block0, include/audiblelight_hip.h): al_plan_chunk."""
         n = len(self.events)
         step = n if not chunk_events or chunk_events <= 0 else int(chunk_events)
-        out = []
-        for e0 in range(0, max(n, 1), max(step, 1)):
-            e1 = min(e0 + step, n)
-            ev = self.events[e0:e1]
-            s0 = int(ev["stream0"][0]) if len(ev) else 0
-            s1 = int(ev["stream0"][-1] + max(int(ev["n_streams"][-1]), 1)) if len(ev) else 0
-            st = self.streams[s0:s1]
-            conv = ev["n_streams"] > 0
-            # streams of convolved events (pseudo-streams of zero-emitter events carry no spectra)
-            is_conv = np.zeros(len(st), dtype=bool)
-            for k in np.flatnonzero(conv):
-                a = int(ev["stream0"][k]) - s0
-                is_conv[a: a + int(ev["n_streams"][k])] = True
-            cs = st[is_conv]
-            em0 = int(cs["emitter"].min()) if len(cs) else 0
-            em1 = int(cs["emitter"].max()) + 1 if len(cs) else 0
-            x0 = int(cs["xspec_base"].min()) if len(cs) else 0
-            x1 = int((cs["xspec_base"] + cs["n_j"]).max()) if len(cs) else 0
-            y0 = int(ev["yspec_base"][conv].min()) if conv.any() else 0
-            y1 = int((ev["yspec_base"][conv] + self.n_capsules * ev["n_blocks"][conv]).max()) if conv.any() else 0
-            out.append(dict(event0=e0, n_events=e1 - e0, stream0=s0, n_streams=s1 - s0, emitter0=em0,
-                            n_emitters=em1 - em0, xspec_block0=x0, xspec_blocks=x1 - x0, yspec_block0=y0,
-                            yspec_blocks=y1 - y0, max_blocks=int(ev["n_blocks"].max()) if len(ev) else 0,
-                            max_nj=int(st["n_j"].max()) if len(st) else 0))
+        if n == 0:
+            return [dict(event0=0, n_events=0, stream0=0, n_streams=0, emitter0=0, n_emitters=0, xspec_block0=0, xspec_blocks=0,
+                         yspec_block0=0, yspec_blocks=0, max_blocks=0, max_nj=0)]
+        lib, handle, out = _lib(), self._c_plan(), []
+        try:
+            for e0 in range(0, n, max(step, 1)):
+                ch = _hip.AlChunk()
+                lib.call("al_plan_chunk", handle, e0, min(step, n - e0), ct.byref(ch))
+                out.append({name: int(getattr(ch, name)) for name, _ in _hip.AlChunk._fields_})
+        finally:
+            lib.call("al_plan_destroy", handle)
         return out
 
     def workspace_bytes(self) -> int:

@@ -48,3 +48,70 @@ def test_c_host_renders_what_the_oracle_renders(tmp_path, C, E, La, Lir, log2_bl
             assert_parity(got[c], want[c], TOL, what=(e, c))
         want_scene += want
     assert_parity(scene, want_scene, TOL)
+
+
+PLANNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_caller", "_build", "render_planned")
+
+
+@pytest.mark.parametrize("log2_block,chunk_events,fused,lir,expect_code", [(10, 0, 0, 2600, 612), (10, 2, 0, 2600, 612),
+                                                                              (13, 0, 1, 30_001, 10508), (13, 3, 1, 30_001, 10508),
+                                                                              (13, 0, 0, 30_001, 612)],
+                         ids=["B1024_one_batch", "B1024_chunks_of_2", "B8192_fused_moving", "B8192_fused_moving_chunks_of_3", "B8192_stored_spectra"])
+def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fused, lir, expect_code):
+    """tests/c_caller/render_planned.c: static + moving + tiled events, an ambience and a chunked batch from a C host that
+    takes EVERY table from the library's planner (al_plan_create / al_plan_chunk / al_plan_emitter_parts / al_plan_mixdown);
+    every row of every event and of the scene against the oracle.  At B = 8192 the moving events go through k_moving_fused."""
+    if not os.path.exists(PLANNED):
+        import __graft_entry__
+
+        __graft_entry__.build_c_caller()
+    from tests.conftest import assert_parity
+
+    B = 1 << log2_block
+    rng = np.random.default_rng(log2_block * 10 + chunk_events)
+    C, sr, ref_db, duration, amb_db = 3, 48000.0, -60.0, 9.0 * B / 48000.0 + 0.3, -55.0
+    kinds = [(int(4.6 * B) + 3, 1, False), (7 * B, 12, True), (B + 5, 0, False), (3 * B - 7, 1, False), (int(5.5 * B), 9, True)]
+    events, col = [], 0
+    for n, ne, mv in kinds:
+        events.append(dict(n=n, ne=ne, e0=col, mv=mv, snr=float(rng.uniform(5, 30)), start=float(rng.uniform(0, duration - n / sr))))
+        col += ne
+    N = col
+    clips = [rng.standard_normal(ev["n"]).astype(np.float32) for ev in events]
+    clips = [c / np.abs(c).max() for c in clips]
+    irs = (rng.standard_normal((C, N, lir)) * np.exp(-np.arange(lir) / (lir / 5.0))).astype(np.float32)
+    T = round(duration * sr)
+    noise = rng.standard_normal((C, T)).astype(np.float32)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(src, "wb") as f:
+        np.array([C, len(events), N, lir, log2_block, chunk_events, 1, fused], dtype=np.int32).tofile(f)
+        np.array([ref_db, sr, duration, amb_db], dtype=np.float32).tofile(f)
+        for ev in events:
+            np.array([ev["n"], ev["ne"], ev["e0"], int(ev["mv"])], dtype=np.int32).tofile(f)
+            np.array([ev["snr"], ev["start"]], dtype=np.float32).tofile(f)
+        for c in clips:
+            c.tofile(f)
+        irs.tofile(f)
+        noise.tofile(f)
+    run = subprocess.run([PLANNED, str(src), str(dst)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    n_chunks = 1 if chunk_events == 0 else -(-len(events) // chunk_events)
+    assert f"in {n_chunks} chunk(s)" in run.stdout and f"fused_moving = {fused}" in run.stdout and f"moving_code = {expect_code}" in run.stdout, run.stdout
+    out = np.fromfile(dst, dtype=np.float32)
+    E = len(events)
+    scale, at = out[:E], E
+    want_spatial = []
+    for i, ev in enumerate(events):
+        got = out[at: at + C * ev["n"]].reshape(C, ev["n"]).astype(np.float64) * float(scale[i])
+        at += C * ev["n"]
+        h = irs[:, ev["e0"]: ev["e0"] + ev["ne"], :].astype(np.float64)
+        # float32(start) is what the C host was given
+        want = orc.render_event(clips[i], h, float(np.float32(ev["snr"])), ref_db=ref_db, is_moving=ev["mv"], duration=ev["n"] / sr, sr=sr)["spatial"]
+        for c in range(C):
+            assert_parity(got[c], want[c], TOL, what=(i, c))
+        want_spatial.append(want)
+    scene = out[at:].reshape(C, T)
+    slots = [(float(np.float32(ev["start"])), float(np.float32(ev["start"])) + ev["n"] / sr) for ev in events]
+    ref = orc.mix_scene(want_spatial, slots, duration, sr, ambiences=[(orc.peak_normalise_rows(noise.astype(np.float64)), amb_db)],
+                        keep_padded=False)["scene"]
+    for c in range(C):
+        assert_parity(scene[c], ref[c], TOL, what=("scene", c))

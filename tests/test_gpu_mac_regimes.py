@@ -111,15 +111,15 @@ def test_moving_regimes(gpu, monkeypatch, log2_block, p_mult, expect):
     mr.run_moving_case(gpu, log2_block, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect)
 
 
-@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(4.3, 10, 14.2, 10604), (11.7, 10, 14.2, 10604), (12.6, 10, 14.2, 10604),
-                                                         (23.9, 10, 14.2, 10604), (2.6, 24, 30.1, 10508), (8.4, 24, 30.1, 10508),
+@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(4.3, 10, 14.2, 612), (23.9, 10, 14.2, 624), (2.6, 24, 30.1, 10508), (8.4, 24, 30.1, 10508),
                                                          (11.72, 24, 30.1, 10508), (17.3, 24, 30.1, 10508), (23.9, 32, 45.4, 10508)],
-                         ids=["nj6_P5", "nj6_P12", "nj6_P13", "nj6_P24", "nj5_P3", "nj5_P9", "nj5_P12", "nj5_P18", "nj5_P24"])
+                         ids=["nj6_P5_stored_spectra", "nj6_P24_stored_spectra", "nj5_P3", "nj5_P9", "nj5_P12", "nj5_P18", "nj5_P24"])
 def test_fused_moving_regimes(gpu, monkeypatch, p_mult, n_irs, k_mult, expect):
-    """k_moving_fused (csrc/al_quad.h; default for sliding-window moving events at B = 8192): the accumulate transforms the IR
-    partitions itself in the quad layout, no IR spectrum is written (the poisoned workspace stays poisoned).  Both
-    instantiations (streams of at most 5 / 6 blocks), one, two and three passes over the partitions with a ragged last pass,
-    ragged last partition, IRs whose late partitions reach no kept block; every row against the oracle."""
+    """k_moving_fused (csrc/al_quad.h; default at B = 8192 for sliding-window moving events whose streams have at most 5 signal
+    blocks): the accumulate transforms the IR partitions itself in the quad layout, no IR spectrum is written (the poisoned
+    workspace stays poisoned).  One, two and three passes over the partitions with a ragged last pass, ragged last partition,
+    IRs whose late partitions reach no kept block; streams of 6 blocks stay on the stored-spectra kernel.  Every row against
+    the oracle."""
     monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
     mr.run_moving_case(gpu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=3, E=2)
 

@@ -1443,7 +1443,7 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
 #undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
   if (m.moving_code >= 10000) {
-    if (!al_moving_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_MOVING needs B = 8192, the split + quad layout flags and AL_FLAG_FUSED_NJ5 (streams of at most 5 blocks)");
+    if (!al_moving_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_MOVING needs B = 8192 and the split + quad layout flags");
     return check_error(al::launch_moving_fused(b, stream), "k_moving_fused");
   }
   if (m.moving_code) {
@@ -1468,8 +1468,7 @@ int al_fused_supported(const al_batch *b) {
 int al_moving_fused_supported(const al_batch *b) {
   if (check_batch(b)) return 0;
   return b->log2_block == 13 && b->n_partitions >= 1 && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS &&
-         (b->flags & AL_FLAG_SPLIT_SPECTRA) && (b->flags & AL_FLAG_QUAD_SPECTRA) && (b->flags & AL_FLAG_FUSED_NJ5) &&
-         !(b->flags & AL_FLAG_FUSED_STATIC);
+         (b->flags & AL_FLAG_SPLIT_SPECTRA) && (b->flags & AL_FLAG_QUAD_SPECTRA) && !(b->flags & AL_FLAG_FUSED_STATIC);
 }
 
 int al_mac_synthesis(const al_batch *b, al_stream_t stream) {

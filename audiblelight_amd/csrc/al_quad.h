@@ -27,6 +27,14 @@
 // are L2 hits.  More than PTW partitions are walked in passes of PTW, the later passes adding to the blocks the earlier
 // ones stored (read-modify-write of Y by the thread that wrote it).
 //
+// STATUS (round 4, profiles/r04b_cfg3_fused_first_version_ab.txt, r04c_moving_fused_phase_timing.txt): parity-green on the
+// MI355X against the oracle in every regime, but SLOWER than the path over stored spectra: 6.9 ms + 1.3 ms for the energy-only
+// forward pass against 3.5 + 2.7 ms on cfg3 (8.8 vs 6.9 ms per scene).  Timing builds show why: the phases of a round ADD UP --
+// raw loads 2.7, transforms 1.6, products 1.5, stage 0.6, loop skeleton 1.0 ms -- because with 136 KB of LDS and 256 VGPRs
+// only ONE 512-thread workgroup fits a CU and all its waves are in the same phase between barriers.  A second version
+// (signal blocks parked in LDS, transform image as the stage, next round's samples requested a phase ahead behind LDS-only
+// barriers; commit "k_moving_fused v3 experiment", profiles/r04d_*, r04e_*) measured 9.4 ms.  Opt-in: AL_FUSED_MOVING=1.
+//
 // The IR energies of normalize_irs (synthesize.py:404-428) come from the forward kernel in its energy-only mode
 // (al_batch.emitter_parts[n] = 0): one read-only pass over the IR tensor; the gains must exist before the first product.
 #pragma once
@@ -34,12 +42,6 @@
 
 #include "al_common.h"
 #include "al_fft.h"
-
-// Timing builds: bit 2 no products, bit 4 no look-ahead (every round requests its own samples).  0 = the product.
-// (The first version's phase timings -- loads, transforms, products, stage: profiles/r04c_moving_fused_phase_timing.txt.)
-#ifndef AL_MF_SKIP
-#define AL_MF_SKIP 0
-#endif
 
 namespace al {
 
@@ -72,38 +74,11 @@ struct FoldFactors {
   }
 };
 
-// The raw samples a tile's fold needs from one partition, requested as early as possible (a round before they are folded):
-// 64 floats per thread.  Tile 0 folds pairs (h[2n], h[2n+1]) and (h[2n + 2Q], h[2n + 2Q + 1]), n = tg + 128 m; tiles 1..3 fold
-// h[n + Q j], j < 4.  `ir` points at the partition's first sample, `remaining` = samples left in the IR from there (the loads
-// are clamped into the row, the fold zeroes what lies beyond); `live` = false touches no memory.
-template <bool TILE0>
-__device__ __forceinline__ void issue_raw(const float *__restrict__ ir, int remaining, bool live, int tg, float (&raw)[64]) {
-  constexpr int Q = 2048;
-  if (!live) return;
-  const bool whole = remaining >= 4 * Q;   // group-uniform
-  const int last = remaining - 1;
-#pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    if constexpr (TILE0) {
-      const int t = 2 * (tg + 128 * m);
-      if (whole) {
-        const float2 lo = *reinterpret_cast<const float2 *>(ir + t), hi = *reinterpret_cast<const float2 *>(ir + t + 2 * Q);
-        raw[4 * m] = lo.x; raw[4 * m + 1] = lo.y; raw[4 * m + 2] = hi.x; raw[4 * m + 3] = hi.y;
-      } else {
-        raw[4 * m] = ir[min(t, last)]; raw[4 * m + 1] = ir[min(t + 1, last)];
-        raw[4 * m + 2] = ir[min(t + 2 * Q, last)]; raw[4 * m + 3] = ir[min(t + 2 * Q + 1, last)];
-      }
-    } else {
-      const int n = tg + 128 * m;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) raw[4 * m + j] = whole ? ir[n + Q * j] : ir[min(n + Q * j, last)];
-    }
-  }
-}
-
-// The Q-point transform input of tile TILE from those samples: z[m] at n = tg + 128 m.
+// The Q-point transform input of tile `tile` for one partition: z[m] at n = tg + 128 m.  `ir` points at the partition's first
+// sample, `remaining` = samples left in the IR from there (zeros beyond); `live` = false gives zeros without touching memory.
 template <int TILE>
-__device__ __forceinline__ void fold_raw(const float (&raw)[64], int remaining, bool live, int tg, float2 wb, float2 (&z)[16]) {
+__device__ __forceinline__ void fold_partition(const float *__restrict__ ir, int remaining, bool live, int tg, float2 wb,
+                                               float2 (&z)[16]) {
   constexpr int Q = 2048;
   constexpr FoldFactors ff{};
   constexpr float R2 = 0.70710678118654752440f;
@@ -112,21 +87,33 @@ __device__ __forceinline__ void fold_raw(const float (&raw)[64], int remaining, 
     for (int m = 0; m < 16; ++m) z[m] = make_float2(0.f, 0.f);
     return;
   }
-  const bool whole = remaining >= 4 * Q;
+  const bool whole = remaining >= 4 * Q;   // group-uniform
   const int last = remaining - 1;
+  if constexpr (TILE == 0) {
 #pragma unroll
-  for (int m = 0; m < 16; ++m) {
-    float h0 = raw[4 * m], h1 = raw[4 * m + 1], h2 = raw[4 * m + 2], h3 = raw[4 * m + 3];
-    if constexpr (TILE == 0) {
-      if (!whole) {
-        const int t = 2 * (tg + 128 * m);
-        h0 = t <= last ? h0 : 0.f; h1 = t + 1 <= last ? h1 : 0.f; h2 = t + 2 * Q <= last ? h2 : 0.f; h3 = t + 2 * Q + 1 <= last ? h3 : 0.f;
+    for (int m = 0; m < 16; ++m) {
+      const int t = 2 * (tg + 128 * m);
+      float2 lo, hi;
+      if (whole) {
+        lo = *reinterpret_cast<const float2 *>(ir + t);
+        hi = *reinterpret_cast<const float2 *>(ir + t + 2 * Q);
+      } else {
+        const float a0 = ir[min(t, last)], a1 = ir[min(t + 1, last)], b0 = ir[min(t + 2 * Q, last)], b1 = ir[min(t + 2 * Q + 1, last)];
+        lo = make_float2(t <= last ? a0 : 0.f, t + 1 <= last ? a1 : 0.f);
+        hi = make_float2(t + 2 * Q <= last ? b0 : 0.f, t + 2 * Q + 1 <= last ? b1 : 0.f);
       }
-      z[m] = make_float2(h0 + h2, h1 + h3);
-    } else {
+      z[m] = make_float2(lo.x + hi.x, lo.y + hi.y);
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
       const int n = tg + 128 * m;
-      if (!whole) {
-        h0 = n <= last ? h0 : 0.f; h1 = n + Q <= last ? h1 : 0.f; h2 = n + 2 * Q <= last ? h2 : 0.f; h3 = n + 3 * Q <= last ? h3 : 0.f;
+      float h0, h1, h2, h3;
+      if (whole) {
+        h0 = ir[n]; h1 = ir[n + Q]; h2 = ir[n + 2 * Q]; h3 = ir[n + 3 * Q];
+      } else {
+        const float a0 = ir[min(n, last)], a1 = ir[min(n + Q, last)], a2 = ir[min(n + 2 * Q, last)], a3 = ir[min(n + 3 * Q, last)];
+        h0 = n <= last ? a0 : 0.f; h1 = n + Q <= last ? a1 : 0.f; h2 = n + 2 * Q <= last ? a2 : 0.f; h3 = n + 3 * Q <= last ? a3 : 0.f;
       }
       const float2 w = cmul(wb, make_float2(ff.c[m], -ff.s[m]));    // e^{-i pi n / B}
       const float2 w2 = cmul(w, w);
@@ -147,8 +134,8 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
   using G = FftGeom<11, 16>;
   constexpr int Q = 2048, B = 8192, W = NJW + PTW - 1, NG = 4, ROUNDS = PTW / 4;
   static_assert(PTW % 4 == 0 && G::T == 128, "four 128-thread groups transform four partitions per round");
-  __shared__ float2 img[NG][G::LDS_ELEMS];      // transform images; after the last pass: the partition's tile in natural order (padded)
-  __shared__ float4 xlds[NJW * 2][512];          // the stream's signal blocks, each thread's own 4 slots (read back by their writer only)
+  __shared__ float2 img[NG][G::LDS_ELEMS];
+  __shared__ float2 stage[NG][Q];
   __shared__ int4 tab[64];    // {j_lo, n_j, emitter, xspec_base - xspec_block0}
   __shared__ float gains[64];
   const int tid = threadIdx.x, g = tid >> 7, tg0 = tid & 127;
@@ -192,10 +179,7 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
     const bool first = p0 == 0;     // later passes add to what the earlier ones stored
     Quad4 acc[W];
     int kbase = -1;                 // output block held in acc[0]; -1: the window has not been placed yet
-    float raw[64];                  // the samples of the round after the one being transformed (issue_raw)
-    bool prefetched = false;
     for (int l0 = 0; l0 < ev.n_streams; l0 += 64) {
-      prefetched = false;           // the look-ahead stops at the end of a table chunk
       __syncthreads();
       if (tid < 64 && l0 + tid < ev.n_streams) {
         const al_stream st = b.streams[ev.stream0 + l0 + tid];
@@ -225,18 +209,15 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
           ++kbase;
         }
         const float gn = gains[l];
-        // the stream's signal blocks, times the emitter gain, parked in LDS: live in registers only during the products
-        // (a thread reads back only what it wrote itself: no barrier)
+        Quad4 x[NJW];
 #pragma unroll
         for (int jj = 0; jj < NJW; ++jj) {
-          if (jj < nj) {                                  // workgroup-uniform
-            const float2 *xp = X + (int64_t)(t.w + jj) * B;
-            const float4 a = *reinterpret_cast<const float4 *>(xp), bq = *reinterpret_cast<const float4 *>(xp + 2);
-            xlds[2 * jj][tid] = make_float4(a.x * gn, a.y * gn, a.z * gn, a.w * gn);
-            xlds[2 * jj + 1][tid] = make_float4(bq.x * gn, bq.y * gn, bq.z * gn, bq.w * gn);
-          }
+          x[jj] = load4(X + (int64_t)(t.w + min(jj, nj - 1)) * B);
+          const float sc = jj < nj ? gn : 0.f;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) x[jj].s[i] = make_float2(x[jj].s[i].x * sc, x[jj].s[i].y * sc);
         }
-        const float *irc = b.ir + (int64_t)c * b.ir_stride_c;
+        const float *irn = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)t.z * b.ir_stride_n;
         static_for<ROUNDS>([&](auto r_c) {
           constexpr int r = decltype(r_c)::value;
           if (p0 + 4 * r < pe) {                          // workgroup-uniform: the round has a live partition
@@ -248,89 +229,30 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
             tw.hide_from_hoisting();
             const int p = p0 + 4 * r + g;                 // this group's partition
             const bool live = p < pe;                     // group-uniform
-            const int remaining = b.ir_len - min(p, P - 1) * B;
-            if (!prefetched) {                            // first round of a table chunk: nobody requested its samples yet
-              const float *src = irc + (int64_t)t.z * b.ir_stride_n + (int64_t)min(p, P - 1) * B;
-              if (tile == 0) issue_raw<true>(src, remaining, live, tg, raw);
-              else issue_raw<false>(src, remaining, live, tg, raw);
-            }
             float2 z[16];
+            const float *src = irn + (int64_t)min(p, P - 1) * B;
+            const int remaining = b.ir_len - min(p, P - 1) * B;
             switch (tile) {                               // workgroup-uniform
-              case 0: fold_raw<0>(raw, remaining, live, tg, wb, z); break;
-              case 1: fold_raw<1>(raw, remaining, live, tg, wb, z); break;
-              case 2: fold_raw<2>(raw, remaining, live, tg, wb, z); break;
-              default: fold_raw<3>(raw, remaining, live, tg, wb, z); break;
+              case 0: fold_partition<0>(src, remaining, live, tg, wb, z); break;
+              case 1: fold_partition<1>(src, remaining, live, tg, wb, z); break;
+              case 2: fold_partition<2>(src, remaining, live, tg, wb, z); break;
+              default: fold_partition<3>(src, remaining, live, tg, wb, z); break;
             }
-            // all passes through LDS: the last one leaves the transform in the image in natural order (slot i at pad(i)) AND in
-            // z[m] = Z[tg + 128 m], and ends with a barrier -- the image IS the stage the products read
-            FftPasses<G, -1, 0, false, true>::run(z, img[g], tw, tg);
+            fft_regs_to_regs<G, -1>(z, img[g], tw, tg);   // z[m] = Z[tg + 128 m]; its last LDS reads end with a barrier
             if (tile == 0) {
-              // real-FFT unpacking of tile 0, in place: thread owning k = tg + 128 m (m < 8) reads Z[M - k] from the image and
-              // writes slots k and M - k; nobody else reads or writes either, so no barrier in between (formulas: al_fft.h)
-              constexpr int M = G::M, T = G::T, H = G::H;
-              constexpr PackFactors<G> pf{};
-              float2 *s_ = img[g];
+              real_unpack_store_regs<G>(z, img[g], tw.w0, tg, stage[g]);
+            } else {
 #pragma unroll
-              for (int m = 0; m < H; ++m) {
-                const int k = tg + T * m;
-                if (m == 0 && k == 0) {
-                  const float2 z0 = z[0], zh = z[H];
-                  s_[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
-                  s_[G::pad(M / 2)] = cconj(zh);
-                } else {
-                  const float2 wm = m == 0 ? tw.w0 : cmul(tw.w0, make_float2(pf.c[m], -pf.s[m]));
-                  const float2 zk = z[m], zm = s_[G::pad(M - k)];
-                  const float2 e_ = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                  const float2 d_ = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-                  const float2 wo = cmul(wm, make_float2(d_.y, -d_.x));
-                  s_[G::pad(k)] = cadd(e_, wo);
-                  s_[G::pad(M - k)] = cconj(csub(e_, wo));
-                }
-              }
+              for (int m = 0; m < 16; ++m) stage[g][tg + 128 * m] = z[m];
             }
-            // The NEXT round's samples are requested now and folded a whole accumulate phase later: with one workgroup per CU
-            // and every wave in the same phase nothing else would hide their latency (profiles/r04c_moving_fused_phase_timing.txt:
-            // the loads alone were 2.7 of the first version's 6.9 ms).  Next round = this stream's (r + 1) or the first round of
-            // the next stream of this table chunk that has a partition in this pass.
-            {
-              int nemit = t.z, np_ = p0 + 4 * (r + 1) + g, npe = pe;
-              bool found = (r + 1 < ROUNDS) && (p0 + 4 * (r + 1) < pe);
-              if (!found) {
-                for (int l2 = l + 1; l2 < nl; ++l2) {
-                  const int4 t2 = tab[l2];
-                  const int pe2 = min(min(P, K - t2.x), p0 + PTW);
-                  if (t2.y > 0 && pe2 > p0) { found = true; nemit = t2.z; np_ = p0 + g; npe = pe2; break; }
-                }
-              }
-              prefetched = found && !(AL_MF_SKIP & 16);
-              if (prefetched) {
-                const float *src = irc + (int64_t)nemit * b.ir_stride_n + (int64_t)min(np_, P - 1) * B;
-                const int rem2 = b.ir_len - min(np_, P - 1) * B;
-                const int tg2 = opaque_lane(tg0);
-                if (tile == 0) issue_raw<true>(src, rem2, np_ < npe, tg2, raw);
-                else issue_raw<false>(src, rem2, np_ < npe, tg2, raw);
-              }
-            }
-            if (tile == 0) block_barrier<true>();         // tile 0's unpacking wrote the image after the last pass's barrier
-            Quad4 x[NJW];
-#pragma unroll
-            for (int jj = 0; jj < NJW; ++jj) {
-              if (jj < nj) {
-                const float4 a = xlds[2 * jj][tid], bq = xlds[2 * jj + 1][tid];
-                x[jj].s[0] = make_float2(a.x, a.y); x[jj].s[1] = make_float2(a.z, a.w);
-                x[jj].s[2] = make_float2(bq.x, bq.y); x[jj].s[3] = make_float2(bq.z, bq.w);
-              }
-            }
+            __syncthreads();
             static_for<4>([&](auto gg_c) {
               constexpr int gg = decltype(gg_c)::value, pp = 4 * r + gg;
               if (p0 + pp < pe) {                         // workgroup-uniform
-                Quad4 h;                                  // slots 4 tid .. 4 tid + 3 of partition gg: contiguous inside one padded 16-group
-                const float2 *hp = &img[gg][4 * tid + (tid >> 2)];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) h.s[i] = hp[i];
+                const Quad4 h = load4(&stage[gg][4 * tid]);
 #pragma unroll
                 for (int jj = 0; jj < NJW; ++jj) {
-                  if ((AL_MF_SKIP & 4) || jj >= nj) continue;   // workgroup-uniform: blocks past the stream's last are not multiplied
+                  if (jj >= nj) continue;                 // workgroup-uniform: blocks past the stream's last are not multiplied
                   if (bin0_wave) {                        // (DC, Nyquist) packed in slot 0 of tile 0: two real products in lane 0
                     const float2 a0 = acc[jj + pp].s[0];
                     cfma_pk(acc[jj + pp].s[0], x[jj].s[0], h.s[0]);
@@ -344,8 +266,7 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
                 }
               }
             });
-            block_barrier<true>();                        // the images are free for the next round's first pass (LDS-only
-                                                          // barriers throughout: the look-ahead loads stay in flight)
+            // no barrier here: the next write of the stage lies behind the barriers of the next round's transform passes
           }
         });
       }
@@ -363,19 +284,16 @@ __global__ __launch_bounds__(512) void k_moving_fused(al_batch b) {
   }
 }
 
-// One instantiation: streams of at most 5 signal blocks (cfg3: cross-fade windows of 2.9 blocks), passes of 8 partitions.  The
-// LDS budget (four transform images + the stream's signal blocks: 150 KB of 160) is what bounds NJW; longer streams stay
-// on k_spectral_mac_moving over stored spectra.
-#ifndef AL_MF_PTW5
-#define AL_MF_PTW5 8   /* partitions per pass (A/B switch of the timing builds) */
-#endif
-int moving_fused_code(const al_batch *b) { (void)b; return 10000 + 500 + AL_MF_PTW5; }
+// Which instantiation takes a batch: NJW = 5 (cfg3: cross-fade windows of 2.9 blocks) in passes of 8 partitions, NJW = 6 in
+// passes of 4 (the accumulator window is what fills the register file).
+int moving_fused_code(const al_batch *b) { return 10000 + ((b->flags & AL_FLAG_FUSED_NJ5) ? 508 : 604); }
 
 hipError_t launch_moving_fused(const al_batch *b, hipStream_t stream) {
   const int64_t pairs = (int64_t)b->n_capsules * b->n_events, ids = (pairs + 7) / 8 * 8 * 4;
   if (ids > 0x7fffffff) return hipErrorInvalidValue;
   const dim3 grid((unsigned)ids);
-  hipLaunchKernelGGL((k_moving_fused<5, AL_MF_PTW5>), grid, dim3(512), 0, stream, *b);
+  if (b->flags & AL_FLAG_FUSED_NJ5) hipLaunchKernelGGL((k_moving_fused<5, 8>), grid, dim3(512), 0, stream, *b);
+  else hipLaunchKernelGGL((k_moving_fused<6, 4>), grid, dim3(512), 0, stream, *b);
   return hipGetLastError();
 }
 

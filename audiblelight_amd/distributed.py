@@ -105,6 +105,51 @@ def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, devic
     return {i: v.cpu().numpy() for i, v in out.items()}
 
 
+def render_and_gather_overlapped(render_fn: Callable[[int], "object"], n_items: int, shape, dst: int = 0, device=None):
+    """Render this rank's scenes and collect ALL ``n_items`` (C, T) float32 buffers on rank ``dst`` WHILE the rendering goes
+    on: a scene is sent the moment its kernels are enqueued (the send is stream-ordered behind them), instead of all of them
+    after the last one (``gather_buffers``).  All scenes have the same ``shape`` (BASELINE configs[3]: a batch of equal scenes).
+
+    The root posts its receives up front, one grouped launch per ROUND (round r = scenes r * world .. r * world + world - 1,
+    one from every peer, each arriving over that peer's own xGMI link); a pair of ranks matches sends and receives in issue
+    order, and every peer sends its scenes in ascending order.  ``render_fn(i)`` returns scene i's buffer on this rank's device
+    (a tensor that stays valid until this function returns).  Returns {index: tensor} on ``dst``, None elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    backend = dist.get_backend()
+    dev = device if device is not None else (torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu"))
+    c, t = int(shape[0]), int(shape[1])
+    out: Dict[int, object] = {}
+    reqs, keep = [], []
+    if rank == dst:
+        for r in range(-(-n_items // world)):
+            ops = []
+            for owner in range(world):
+                idx = r * world + owner
+                if idx >= n_items or owner == dst:
+                    continue
+                out[idx] = torch.empty((c, t), dtype=torch.float32, device=dev)
+                ops.append(dist.P2POp(dist.irecv, out[idx].view(-1), owner))
+            if ops:
+                reqs += dist.batch_isend_irecv(ops)
+    for idx in shard_indices(n_items, rank, world):
+        buf = render_fn(idx)
+        buf = (torch.from_numpy(np.ascontiguousarray(buf)) if isinstance(buf, np.ndarray) else buf).to(dev, dtype=torch.float32)
+        if tuple(buf.shape) != (c, t):
+            raise ValueError(f"scene {idx} has shape {tuple(buf.shape)}, the overlapped gather was set up for {(c, t)}")
+        if rank == dst:
+            out[idx] = buf
+        else:
+            flat = buf.contiguous().view(-1)
+            keep.append(flat)
+            reqs += dist.batch_isend_irecv([dist.P2POp(dist.isend, flat, dst)])
+    for req in reqs:
+        req.wait()
+    return out if rank == dst else None
+
+
 def render_scenes(n_scenes: int, render_fn: Callable[[int], "object"], gather: bool = True, dst: int = 0):
     """Render scenes [0, n_scenes) across the process group.
 

@@ -447,12 +447,13 @@ class Renderer:
             tables += [np.array([src.prescale for src in sources], dtype=np.float32),
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
         parts = plan.emitter_parts() if os.environ.get("AL_TRIM_PARTITIONS", "1") == "1" else None
-        # Sliding-window moving events through k_moving_fused (csrc/al_quad.h): the accumulate transforms the IR partitions
-        # itself, their spectra are never written (cfg3: 36 -> 17 GB per scene).  Needs the split + quad layout (B = 8192).
+        # EXPERIMENTAL, off by default (AL_FUSED_MOVING=1): sliding-window moving events through k_moving_fused (csrc/al_quad.h).
+        # The accumulate transforms the IR partitions itself, their spectra are never written (cfg3: 36 -> 17 GB per scene) --
+        # but one 512-thread workgroup per CU cannot overlap its load / transform / product phases, and it measures 8.8 ms
+        # against 6.9 ms per cfg3 scene (profiles/r04b_cfg3_fused_first_version_ab.txt).  Needs the split + quad layout (B = 8192).
         fused_static = os.environ.get("AL_FUSED", "0") == "1"
-        fuse_moving = (os.environ.get("AL_FUSED_MOVING", "1") == "1" and plan.log2_block == 13 and not fused_static
+        fuse_moving = (os.environ.get("AL_FUSED_MOVING", "0") == "1" and plan.log2_block == 13 and not fused_static
                        and os.environ.get("AL_SPLIT", "1") == "1" and 1 <= P <= SPARSE_MAX_PARTITIONS)
-        fuse_moving = fuse_moving and 0 < plan.max_nj_sliding() <= 5     # the kernel keeps a stream's blocks in LDS: 5 is what fits
         fused_parts = plan.fused_moving_parts(parts) if fuse_moving else None
         fuse_moving = fused_parts is not None
         if fuse_moving:
@@ -499,7 +500,7 @@ class Renderer:
             for desc in descs:
                 desc.flags |= _hip.FLAG_SPLIT_SPECTRA
                 if fuse_moving:
-                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | _hip.FLAG_FUSED_NJ5
+                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
                 elif plan.log2_block == 13 and os.environ.get("AL_QUAD", "0") == "1":   # A/B + test switch: the quad layout alone
                     desc.flags |= _hip.FLAG_QUAD_SPECTRA
         # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes

@@ -807,6 +807,35 @@ def run_scene_batch_mode(ctx):
             return scene_tensor(mix, sc, mix_plan, emulate, torch)
 
         out["gather"], ok = gather_and_validate(ctx, r, None, rerender_item, n_items=args.total_scenes, local=local)
+        # ... and the same collection OVERLAPPED with one more step of rendering: every scene is sent the moment it is
+        # enqueued, rank 0 has its receives posted up front (distributed.render_and_gather_overlapped).  gather_overlap_ms is what
+        # the collection costs a step once it hides behind the rendering (max over ranks), against `ms` above for doing it afterwards.
+        def render_into(idx):
+            j = mine.index(idx)
+            sc, batch, mix, mix_plan, _pl = sets[j % n_sets]
+            batch.run()
+            mix.run()
+            if emulate:
+                outputs[j][:n_out] = mix.scene[:n_out]
+            else:
+                outputs[j][:n_out].copy_(mix.scene[:n_out], non_blocking=True)
+            return as_t(outputs[j])
+
+        ctx["barrier"]()
+        t0 = time.perf_counter()
+        got = distributed.render_and_gather_overlapped(render_into, args.total_scenes, (scene0.n_capsules, sets[0][3].n_samples))
+        ctx["device_sync"]()
+        over_ms = ctx["reduce_max"]((time.perf_counter() - t0) * 1e3)
+        step_ms = float(np.median(rep_s)) / args.steps * 1e3
+        rec = {"step_with_gather_ms": over_ms, "step_alone_ms": step_ms, "gather_overlap_ms": over_ms - step_ms}
+        if rank == 0:
+            same = sorted(got) == list(range(args.total_scenes))
+            for item in sorted({i for i in (1, args.total_scenes - 1) if 0 < i < args.total_scenes and i % world != 0}):
+                want = rerender_item(item)
+                same = same and bool(torch.equal(got[item].to(want.device), want))
+            rec["bit_exact"] = same
+            ok = ok and same
+        out["gather"]["overlapped"] = rec
         out["_failed"] = not ok
     return out
 

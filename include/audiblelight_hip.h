@@ -58,9 +58,9 @@ extern "C" {
                                     k_moving_fused, which transforms the IR partitions itself: their spectra are never written.
                                     The caller sets emitter_parts[n] = 0 for the IR columns of those events (the forward kernel
                                     then only takes their energies for normalize_irs).  Needs al_moving_fused_supported(b) != 0 */
-#define AL_FLAG_FUSED_NJ5 1024   /* the caller's promise that goes with AL_FLAG_FUSED_MOVING: every stream of every sliding-window event has
-                                    at most 5 signal blocks (al_plan_info.max_nj_sliding; the host knows the stream table, the library
-                                    does not).  k_moving_fused keeps a stream's blocks in LDS beside its transform images: 5 is what fits */
+#define AL_FLAG_FUSED_NJ5 1024   /* with AL_FLAG_FUSED_MOVING: every stream of every sliding-window event has at most 5 signal blocks
+                                    (al_plan_info.max_nj_sliding; the host knows the stream table, the library does not):
+                                    k_moving_fused<5,8> (8 partitions per pass) instead of <6,4> */
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
@@ -215,14 +215,14 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequenc
  * staged through LDS by registers, k_spectral_mac_static_lds<12,P> (more than 24 blocks) or <12,ceil(P/2),2> (13..16
  * partitions without hspec_zero_block), 4: staged by LDS-DMA, k_spectral_mac_static_glds (13..21 partitions as two or three
  * units per capsule, any clip length; needs hspec_zero_block >= 0); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 10000 + 100*NJW + PTW for
- * the IR-transform-fused one (AL_FLAG_FUSED_MOVING: k_moving_fused<5,PTW>, PTW = 8 partitions per pass: 10508), 0 = not launched. */
+ * the IR-transform-fused one (AL_FLAG_FUSED_MOVING: k_moving_fused<NJW,PTW>, PTW partitions per pass: 10508 / 10604), 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
 /* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.
  * al_fused_supported: 1 if this batch can use it (B = 8192, both zero blocks given, static events present). */
 int al_fused_supported(const al_batch *b);
 /* 1 if the batch can run with AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_MOVING: B = 8192, at most AL_SPARSE_MAX_PARTITIONS partitions,
- * split + quad layout flags and AL_FLAG_FUSED_NJ5 set */
+ * split + quad layout flags set */
 int al_moving_fused_supported(const al_batch *b);
 int al_mac_synthesis(const al_batch *b, al_stream_t stream);
 int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */

@@ -1,4 +1,4 @@
-# cfg3 with the IR-transform-fused moving accumulate (default at B = 8192) against round 3's path over stored IR spectra
+# cfg3 with the IR-transform-fused moving accumulate (AL_FUSED_MOVING=1) against the default path over stored IR spectra
 # (AL_FUSED_MOVING=0), same box, alternating:   gpurun -- 'bash profiles/tools/cfg3_fused_ab.sh r04b'
 R=${GRAFT_REPO_ROOT:-.}; TAG=${1:-r04}; cd $R
 Q="--config cfg3 --steps 20 --warmup 4 --repeats 3 --cpu-events 0 --cpu-workers 0 --dropin 0 --end-to-end 0 --other-configs 0"

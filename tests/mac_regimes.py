@@ -51,7 +51,7 @@ GLDS_CASES += [("glds_cfg2_shape", 3121204, 23.44, 11.72, 5, 2), ("glds_ragged_s
 # k_spectral_mac_static_lds<12,{7,8},2>: 13..16 partitions for a caller that gave no all-zero block (hspec_zero_block = -1)
 NO_ZERO_BLOCK_CASES = [(f"no_zero_block_P{P}", 3120000 + 100 * P + 3, 20.6, P - 0.37, 2, 1) for P in (13, 14, 15, 16)]
 MOVING_CODES = [612, 624]       # asserted by test_moving_regimes / test_cfg3_regime_all_rows
-FUSED_MOVING_CODES = [10508]   # k_moving_fused<5,8> (csrc/al_quad.h): default at B = 8192 for sliding-window events with streams of at most 5 blocks
+FUSED_MOVING_CODES = [10508, 10604]   # k_moving_fused<5,8> / <6,4> (csrc/al_quad.h; opt-in with AL_FUSED_MOVING=1 at B = 8192)
 # codes the GPU tests assert beyond the tables above: cfg4's <12,6,2>, cfg5's tile kernel with two full partition tiles
 EXTRA_STATIC_CODES = [3120602, 1121202]
 

@@ -105,22 +105,21 @@ def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
 @pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (11.7, 612), (12.6, 624), (23.9, 624), (24.2, 0)],
                          ids=["P5", "P12", "P13", "P24", "P25_tile_kernel"])
 def test_moving_regimes(gpu, monkeypatch, log2_block, p_mult, expect):
-    """The sliding-window accumulate over STORED IR spectra (k_spectral_mac_moving): the default below B = 8192, the A/B
-    reference of the fused kernel (AL_FUSED_MOVING=0) at B = 8192."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "0")
+    """The sliding-window accumulate over stored IR spectra (k_spectral_mac_moving): the default at every block size."""
+    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
     mr.run_moving_case(gpu, log2_block, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect)
 
 
-@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(4.3, 10, 14.2, 612), (23.9, 10, 14.2, 624), (2.6, 24, 30.1, 10508), (8.4, 24, 30.1, 10508),
+@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(4.3, 10, 14.2, 10604), (11.7, 10, 14.2, 10604), (12.6, 10, 14.2, 10604),
+                                                         (23.9, 10, 14.2, 10604), (2.6, 24, 30.1, 10508), (8.4, 24, 30.1, 10508),
                                                          (11.72, 24, 30.1, 10508), (17.3, 24, 30.1, 10508), (23.9, 32, 45.4, 10508)],
-                         ids=["nj6_P5_stored_spectra", "nj6_P24_stored_spectra", "nj5_P3", "nj5_P9", "nj5_P12", "nj5_P18", "nj5_P24"])
+                         ids=["nj6_P5", "nj6_P12", "nj6_P13", "nj6_P24", "nj5_P3", "nj5_P9", "nj5_P12", "nj5_P18", "nj5_P24"])
 def test_fused_moving_regimes(gpu, monkeypatch, p_mult, n_irs, k_mult, expect):
-    """k_moving_fused (csrc/al_quad.h; default at B = 8192 for sliding-window moving events whose streams have at most 5 signal
-    blocks): the accumulate transforms the IR partitions itself in the quad layout, no IR spectrum is written (the poisoned
-    workspace stays poisoned).  One, two and three passes over the partitions with a ragged last pass, ragged last partition,
-    IRs whose late partitions reach no kept block; streams of 6 blocks stay on the stored-spectra kernel.  Every row against
-    the oracle."""
-    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
+    """k_moving_fused (csrc/al_quad.h; opt-in with AL_FUSED_MOVING=1 at B = 8192): the accumulate transforms the IR partitions
+    itself in the quad layout, no IR spectrum is written (the poisoned workspace stays poisoned).  Both instantiations (streams
+    of at most 5 / 6 blocks), one, two and three passes over the partitions with a ragged last pass, ragged last partition,
+    IRs whose late partitions reach no kept block; every row against the oracle."""
+    monkeypatch.setenv("AL_FUSED_MOVING", "1")
     mr.run_moving_case(gpu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=3, E=2)
 
 
@@ -172,14 +171,14 @@ def test_default_layout_per_block_size(gpu, monkeypatch):
 def test_cfg3_regime_all_rows(gpu):
     """cfg3's own regime: B = 8192, P = 12 partitions (2 s RIR), 32 IRs per event, 7.75 s clips; 2 events x 4 capsules,
     every row against the oracle (the full config differs only in the event / capsule counts)."""
-    res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=10508, C=4, E=2)
+    res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=612, C=4, E=2)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
 
 
-def test_cfg3_regime_all_rows_stored_spectra(gpu, monkeypatch):
-    """The same through the forward transform + k_spectral_mac_moving<6,12,1> (round 3's path, AL_FUSED_MOVING=0)."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "0")
-    res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=612, C=4, E=2)
+def test_cfg3_regime_all_rows_fused_kernel(gpu, monkeypatch):
+    """The same through k_moving_fused<5,8> (AL_FUSED_MOVING=1: the IR partitions transformed inside the accumulate)."""
+    monkeypatch.setenv("AL_FUSED_MOVING", "1")
+    res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=10508, C=4, E=2)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
 
 

@@ -176,6 +176,8 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert out["scaling"] == "strong" and out["config"]["total_scenes"] == 4 and out["config"]["scenes_this_rank"] == 2
     assert out["gather"]["validated_against_local_rerender"] == {"1": True, "3": True} and out["gather"]["bit_exact"]
     assert out["gather"]["bytes_total"] == 4 * (4 * 12000 * 4)      # ALL four (4 capsules x 12 000 samples) scenes arrived
+    ov = out["gather"]["overlapped"]                                # the same collection overlapped with one more step of rendering
+    assert ov["bit_exact"] and ov["step_with_gather_ms"] > 0 and "gather_overlap_ms" in ov
     # SURVEY 8e row 2 as a mode: ONE scene, capsule rows split over the ranks, two all-reduces inside the step
     out = run(["--shard", "capsules", "--repeats", "1"])
     assert out["config"]["shard"] == "capsules" and out["config"]["capsules_this_rank"] == 2 and out["scaling"] == "strong"
@@ -184,6 +186,45 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
     bad = subprocess.run(cmd, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_eight_ranks_scene_batch_index_arithmetic():
+    """BASELINE configs[3]'s launch shape -- eight ranks, a batch of scenes split round-robin, rank 0 receiving from SEVEN peers --
+    on gloo with the host-emulated kernels at a reduced scene size: 19 scenes (uneven shares: three ranks own 3, five own 2),
+    every one gathered at the end AND once more overlapped with the rendering (receives posted per round up front), the
+    gathered buffers of scenes 1 and 18 compared bit for bit with rank 0's own re-render; and the N = 1 run of the same command
+    makes the same C-ABI calls per step as every rank of the N = 8 run."""
+    import json
+    import subprocess
+    import sys
+
+    from tests import hostemu
+
+    hostemu.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(AL_BENCH_EMULATE="1", AL_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    base = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--repeats", "1", "--config", "cfg1",
+            "--scale", "0.05", "--cpu-events", "0", "--cpu-workers", "0", "--end-to-end", "0", "--dropin", "0"]
+
+    def run(extra):
+        res = subprocess.run(base + extra, env=env, capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-3000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1
+        return json.loads(lines[0])
+
+    out = run(["--gpus", "8", "--total-scenes", "19"])
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["total_scenes"] == 19 and out["config"]["scenes_this_rank"] == 3
+    g = out["gather"]
+    assert g["ranks_seen"] == list(range(8)) and g["bytes_total"] == 19 * (4 * 12000 * 4)
+    assert g["validated_against_local_rerender"] == {"1": True, "18": True} and g["bit_exact"] and g["overlapped"]["bit_exact"]
+    assert len(out["timing"]["ms_per_step_by_rank_last_repeat"]) == 8
+    weak8, one = run(["--gpus", "8"]), run(["--gpus", "1"])
+    assert weak8["n_gpus"] == 8 and weak8["gather"]["ranks_seen"] == list(range(8)) and weak8["gather"]["bit_exact"]
+    assert weak8["gather"]["validated_against_local_rerender"] == {"1": True, "7": True}
+    assert weak8["config"]["step_calls"] == one["config"]["step_calls"] and one["n_gpus"] == 1
+    assert weak8["config"]["workload"] == one["config"]["workload"]
 
 
 def test_header_is_plain_c_and_the_c_host_links():

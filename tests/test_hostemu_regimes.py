@@ -62,13 +62,13 @@ def test_emu_moving_regimes(emu, p_mult, expect):
     mr.run_moving_case(emu, 10, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect, C=2, E=1)
 
 
-@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(2.6, 5, 6.3, 10508), (9.3, 12, 15.2, 10508), (12.4, 24, 30.1, 10508)],
-                         ids=["nj5_P3", "nj5_P10_two_passes", "nj5_P13_two_passes"])
+@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(2.6, 5, 6.3, 10508), (9.3, 8, 11.6, 10604), (12.4, 24, 30.1, 10508)],
+                         ids=["nj5_P3", "nj6_P10_three_passes", "nj5_P13_two_passes"])
 def test_emu_fused_moving_kernel(emu, monkeypatch, p_mult, n_irs, k_mult, expect):
     """k_moving_fused (csrc/al_quad.h, B = 8192) under emulation: the fold of a partition into each quad tile, the four
     2048-point transforms per round, the real-FFT unpacking of tile 0, the LDS stage, passes over the partitions that add to
     stored blocks; the IR spectra workspace stays poisoned.  Every row against the oracle."""
-    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
+    monkeypatch.setenv("AL_FUSED_MOVING", "1")
     mr.run_moving_case(emu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=2, E=1)
 
 

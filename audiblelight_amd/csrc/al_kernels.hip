@@ -118,12 +118,10 @@ template <> struct BinVec<2> {
 
 // k_spectral_mac_static takes the one-emitter events when the flag is set and the partitions fit one register tile
 __host__ __device__ __forceinline__ bool static_mac_active(const al_batch &b) {
-  // up to 24 partitions through the LDS-DMA kernel (it reads the rows past an odd partition count from the all-zero block),
-  // up to 16 through the register-staged one when the caller gave no zero block.  22..24 (cfg5) take k-tiles of EIGHT blocks:
-  // the 31-block signal window then fits the registers of a two-k-tile workgroup (217 VGPRs, no scratch), where k-tiles of 12
-  // needed three window blocks per end in LDS and lost to the tile kernel (profiles/r03_p24_ab.txt); the tile kernel re-reads
-  // the window from L2 for every capsule and partition tile (73 GB of L2 traffic per cfg5 scene for 26 GB of HBM traffic)
-  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= (b.hspec_zero_block >= 0 ? 24 : 16) && b.log2_block >= 9;
+  // up to 21 partitions through the LDS-DMA kernel (it reads the rows past an odd partition count from the all-zero block),
+  // up to 16 through the register-staged one when the caller gave no zero block.  22..24 stay on the tile kernels: three
+  // units of 8 fit (ends of the 35-block window in LDS) but only tie them at C = 32 and lose 5 % on cfg5 (profiles/r03_p24_ab.txt)
+  return (b.flags & AL_FLAG_STATIC_MAC) && b.n_partitions <= (b.hspec_zero_block >= 0 ? 21 : 16) && b.log2_block >= 9;
 }
 
 // KSPLIT: every k-tile is its own workgroup (blockIdx.y = c * n_ktiles + tile) instead of a loop inside the thread.
@@ -1259,8 +1257,7 @@ MacPlan plan_mac(const al_batch *b) {
   if (al::static_mac_active(*b)) {
     const int P = b->n_partitions;
     // enough workgroups to fill the chip: split the capsule loop for small batches
-    const int kt = P > 21 ? 8 : 12;                       // blocks per k-tile: 8 where the window of 22..24 partitions must fit registers
-    const int n_ktiles = (b->max_blocks + kt - 1) / kt, base = (bins / 512) * n_ktiles * b->n_events;
+    const int n_ktiles = (b->max_blocks + 11) / 12, base = (bins / 512) * n_ktiles * b->n_events;
     int n_cs = 1;
     while (n_cs < b->n_capsules && base * n_cs < 1024) n_cs *= 2;
     if (n_cs > b->n_capsules) n_cs = b->n_capsules;
@@ -1272,7 +1269,7 @@ MacPlan plan_mac(const al_batch *b) {
       // k-tiles per workgroup.  Fed by LDS-DMA (k_spectral_mac_static_glds: no staging registers, so the 32-block signal window
       // of 21 partitions fits; profiles/r03_p24_ab.txt) when the batch has an all-zero block for the rows past an odd count,
       // else (13..16 only) by the register-staged ring of k_spectral_mac_static_lds.
-      const int units = P > 16 ? 3 : 2;                   // 22..24: three units of 8 per capsule, k-tiles of 8 blocks
+      const int units = P > 16 ? 3 : 2;
       m.static_kind = b->hspec_zero_block >= 0 ? MAC_STATIC_GLDS : MAC_STATIC_LDS_UNITS;
       m.static_pt = (P + units - 1) / units;
       m.static_grid = dim3(bins / 512, n_pairs, b->n_events * n_cs);
@@ -1399,8 +1396,7 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
     if (P <= 14) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);
     else if (P <= 16) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 8, 2>), m.static_grid, dim3(512), 0, stream, *b);
     else if (P <= 18) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 6, 3>), m.static_grid, dim3(512), 0, stream, *b);
-    else if (P <= 21) hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 3, true, 2>), m.static_grid, dim3(512), 0, stream, *b);
-    else hipLaunchKernelGGL((al::k_spectral_mac_static_glds<8, 8, 3, true, 0, 2>), m.static_grid, dim3(512), 0, stream, *b);
+    else hipLaunchKernelGGL((al::k_spectral_mac_static_glds<12, 7, 3, true, 2>), m.static_grid, dim3(512), 0, stream, *b);
     if (int rc = check_launch("k_spectral_mac_static_glds")) return rc;
   } else if (m.static_kind == MAC_STATIC_LDS_UNITS) {
     if (m.static_pt == 7) hipLaunchKernelGGL((al::k_spectral_mac_static_lds<12, 7, 2>), m.static_grid, dim3(512), 0, stream, *b);

@@ -510,10 +510,9 @@ class Renderer:
                 if self.lib.call("al_fused_supported", ct.byref(desc)):
                     desc.flags |= _hip.FLAG_FUSED_STATIC
         # One-emitter (static) events: the capsule-loop accumulate (k_spectral_mac_static), default wherever the partitions
-        # fit its register tile (P <= 24: -7 % on cfg2's accumulate, -14 % on cfg4's, -20..30 % at P = 13..17, -9 % at 19..21;
-        # profiles/r02_mac.txt, r03_p24_ab.txt; 22..24 with k-tiles of 8 blocks: profiles/r04_cfg5_mac_ab.txt.  AL_STATIC_MAC_MAX_P=21
-        # puts 22..24 back on the tile kernel for A/B runs).
-        if os.environ.get("AL_STATIC_MAC", "1") == "1" and plan.n_partitions <= int(os.environ.get("AL_STATIC_MAC_MAX_P", "24")):
+        # fit its register tile (P <= 21: -7 % on cfg2's accumulate, -14 % on cfg4's, -20..30 % at P = 13..17, -9 % at 19..21;
+        # profiles/r02_mac.txt, r03_p24_ab.txt).
+        if os.environ.get("AL_STATIC_MAC", "1") == "1" and plan.n_partitions <= int(os.environ.get("AL_STATIC_MAC_MAX_P", "21")):
             for desc in descs:
                 if desc.flags & _hip.FLAG_FUSED_STATIC:
                     continue

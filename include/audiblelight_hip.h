@@ -47,7 +47,7 @@ extern "C" {
 #define AL_FLAG_SPLIT_SPECTRA 32 /* spectra in the split layout of csrc/al_split.h (even bins | odd bins, every window transformed
                                     as two half-size FFTs); all of al_ir_spectra / al_signal_spectra / al_block_synthesis must
                                     see the same setting; the accumulate does not care.  B >= 2048; excludes AL_FLAG_FUSED_STATIC */
-#define AL_FLAG_STATIC_MAC 64   /* al_spectral_mac: static (one-emitter) events of batches with at most 24 partitions through k_spectral_mac_static (one workgroup per
+#define AL_FLAG_STATIC_MAC 64   /* al_spectral_mac: static (one-emitter) events of batches with at most 21 partitions through k_spectral_mac_static (one workgroup per
                                    (event, k-tile, bin tile) looping over the capsules); the tile kernels skip them */
 #define AL_FLAG_ONLY_STATIC 128 /* with AL_FLAG_STATIC_MAC: the batch has no multi-emitter event, so the other accumulate
                                    kernels are not launched at all (the host knows the event table, the library does not) */
@@ -213,8 +213,8 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequenc
  * kernel k_spectral_mac), or 3120000 + 100*P + D for the capsule-loop kernels (AL_FLAG_STATIC_MAC, P <= 21 partitions):
  * D = 1: k_spectral_mac_static<12,P,1> (clips of at most 12 blocks), 2: <12,P,2> (13..24 blocks), 3: the partition spectra
  * staged through LDS by registers, k_spectral_mac_static_lds<12,P> (more than 24 blocks) or <12,ceil(P/2),2> (13..16
- * partitions without hspec_zero_block), 4: staged by LDS-DMA, k_spectral_mac_static_glds (13..24 partitions as two or three
- * units per capsule, 22..24 with k-tiles of 8 blocks, any clip length; needs hspec_zero_block >= 0); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 10000 + 100*NJW + PTW for
+ * partitions without hspec_zero_block), 4: staged by LDS-DMA, k_spectral_mac_static_glds (13..21 partitions as two or three
+ * units per capsule, any clip length; needs hspec_zero_block >= 0); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 10000 + 100*NJW + PTW for
  * the IR-transform-fused one (AL_FLAG_FUSED_MOVING: k_moving_fused<NJW,PTW>, PTW partitions per pass: 10508 / 10604), 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */

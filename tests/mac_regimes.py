@@ -25,14 +25,14 @@ STATIC_CASES = [
     ("tile_8_4_1", 80401, 3.0, 2.0),                 # exact multiples: K = 3, P = 2
 ]
 
-# k_spectral_mac_static<12,P,{1,2}> / k_spectral_mac_static_lds<12,P> / _glds<12,ceil(P/2),2> / <12,ceil(P/3),3> / <8,8,3>: EVERY partition count 1..24 in each of
+# k_spectral_mac_static<12,P,{1,2}> / k_spectral_mac_static_lds<12,P> / <12,ceil(P/2),2> / <12,6,3>: EVERY partition count 1..18 in each of
 # the three clip-length regimes that pick a different instantiation (or, for 13..18 partitions, a different grid of the same one):
 # (name, expected code 3120000 + 100*P + {1: one k-tile per workgroup, 2: two, 3: partition spectra staged through LDS},
 #  K multiple, P multiple, capsules, events); one event => the capsule loop is split into ranges (small batch)
 _CLIP_REGIMES = (("one_ktile", 9.3, 1), ("two_ktiles", 20.6, 2), ("beyond_24_blocks", 26.3, 3))
 STATIC_LOOP_CASES = [
     (f"P{P}_{name}", 3120000 + 100 * P + (4 if P > 12 else digit), k_mult + 0.01 * P, P - 0.37, 2 + P % 2, 1 + (P % 3 == 0))
-    for P in range(1, 25) for name, k_mult, digit in _CLIP_REGIMES]
+    for P in range(1, 22) for name, k_mult, digit in _CLIP_REGIMES]
 STATIC_LOOP_CASES += [   # hand-picked edges
     ("cfg2_shape_pair_full", 3121202, 23.44, 11.72, 5, 2),     # K = 24 (two k-tiles in one workgroup), P = 12
     ("pair_ragged_ktile_masked", 3120902, 17.3, 8.6, 3, 2),    # K = 18 (second k-tile half empty), P = 9
@@ -40,7 +40,7 @@ STATIC_LOOP_CASES += [   # hand-picked edges
     ("lds_ring_two_partitions", 3120203, 50.4, 1.7, 2, 1),     # K = 51 (3 workgroups), P = 2; one event: capsule ranges split
     ("two_units_16_long", 3121604, 30.2, 15.4, 2, 1),          # P = 16, K = 31: two workgroups per (event, bin tile)
     ("two_units_one_ktile", 3121404, 7.5, 13.2, 2, 2),         # P = 14, K = 8: the second half of the workgroup idles
-    ("cfg5_shape", 3122404, 23.44, 23.44, 3, 2),               # K = 24, P = 24: cfg5's tile counts (three units of 8, k-tiles of 8 blocks)
+    ("cfg5_shape_tile_kernel", 1121202, 23.44, 23.44, 3, 2),   # K = 24, P = 24: cfg5's tile counts (two full partition tiles)
 ]
 # k_spectral_mac_static_glds<12,P> for at most 12 partitions (AL_EXTRA_FLAGS bit 14: an A/B switch, the default there is the
 # register / register-staged kernel): P = 1..12, clips of 13..24 and of more than 24 blocks

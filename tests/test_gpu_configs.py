@@ -94,8 +94,8 @@ def test_cfg5_64ch_ambience_and_folded_fx(gpu):
 
 
 def test_cfg5_regime_all_rows(gpu):
-    """cfg5's own kernel regime at FULL length: B = 8192, P = 24 partitions (4 s RIR) -> k_spectral_mac_static_glds<8,8,3> (capsule
-    loop, three units of 8 partitions, k-tiles of 8 blocks), K = 24, C = 64 capsules, clip scales folded on the device, the ambience fused into the mixdown
+    """cfg5's own kernel regime at FULL length: B = 8192, P = 24 partitions (4 s RIR) -> k_spectral_mac<12,12,2,KSPLIT> with
+    two full partition tiles, K = 24, C = 64 capsules, clip scales folded on the device, the ambience fused into the mixdown
     over the whole 60 s scene.  2 events built from core.Event(augmentations=[Gain, Invert]) + a white Ambience through
     Scene.generate(); the scene and EVERY row of every event against the oracle."""
     from audiblelight_amd import ambience as amb, augmentation as aug, core, plan as planning, synthetic
@@ -107,7 +107,7 @@ def test_cfg5_regime_all_rows(gpu):
     pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)
     assert pl.log2_block == 13 and pl.n_partitions == 24 and int(pl.events["n_blocks"].max()) == 24
     batch = gpu.prepare(pl, sc.sources(), sc.irs)
-    assert mr.mac_codes(gpu, batch) == (3122404, 0) and mr.is_split(batch)
+    assert mr.mac_codes(gpu, batch) == (1121202, 0) and mr.is_split(batch)
     want_events = [oracle_event(sc, i) for i in range(2)]
     res = batch.run()
     res.check_finite()

@@ -2,7 +2,8 @@ import sys, numpy as np
 sys.path.insert(0, "/root/repo")
 from audiblelight_amd import _hip, engine, plan as planning
 from tests import hostemu
-r = engine.Renderer(lib=_hip.Library(sys.argv[1]), memory=hostemu.NumpyMemory())
+_hip._default = _hip.Library(sys.argv[1])     # the planner (csrc/al_plan.cpp) runs from the sanitized build too
+r = engine.Renderer(lib=_hip._default, memory=hostemu.NumpyMemory())
 rng = np.random.default_rng(0)
 C, L, sr = 3, 700, 8000
 specs, clips, irs, col = [], [], [], 0
@@ -68,3 +69,26 @@ r.lib.call("al_axpy_rows", r.mem.ptr(scene_buf), r.mem.ptr(noise), r.mem.ptr(sca
 assert np.isfinite(r.mem.download(scene_buf)).all()
 syn.set_renderer(None)
 print("asan run ok: round-3 kernels")
+
+# round 4: the planner behind the C ABI ran for every batch above (al_plan_create / al_plan_chunk / al_plan_emitter_parts /
+# al_plan_mixdown from the sanitized library); here the quad spectrum layout and k_moving_fused (csrc/al_quad.h) at B = 8192:
+# two passes over 10 partitions with a ragged last one, streams of 5 and of 6 blocks, tile 0's real-FFT unpacking, and a static
+# event beside it in the quad layout
+os.environ["AL_SPLIT"] = "1"
+os.environ["AL_FUSED_MOVING"] = "1"
+B = 8192
+for n_irs, k_mult in ((6, 7.3), (4, 6.1)):
+    La, Lir = int(k_mult * B), int(9.3 * B)
+    clips = [rng.standard_normal(La).astype(np.float32), rng.standard_normal(2 * B + 5).astype(np.float32)]
+    irs = (rng.standard_normal((1, n_irs + 1, Lir)) * np.exp(-np.arange(Lir) / (Lir / 5.0))).astype(np.float32)
+    specs = [planning.EventSpec(n_samples=La, n_emitters=n_irs, snr=10.0, emitter0=0, is_moving=True, duration=La / 48000),
+             planning.EventSpec(n_samples=len(clips[1]), n_emitters=1, snr=12.0, emitter0=n_irs)]
+    pl = planning.plan_batch(specs, 1, Lir, 48000, log2_block=13)
+    batch = r.prepare(pl, clips, irs)
+    r.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(s_code), ct.byref(m_code))
+    assert m_code.value >= 10000, m_code.value
+    res = batch.run()
+    res.check_finite()
+    print("asan run ok: fused moving accumulate, code", m_code.value, float(np.abs(res.spatial_audio(0)).sum()))
+del os.environ["AL_FUSED_MOVING"]
+print("asan run ok: round-4 kernels")

@@ -106,9 +106,10 @@ class BatchPlan:
     n_partials: int              # entries of 4 floats
     hop: int = config.HOP_SIZE
     fft_size: int = config.FFT_SIZE
-    _specs: Optional[list] = None        # what plan_batch was given (the C planner is re-run from it for the derived tables)
+    _specs: Optional[list] = None        # what plan_batch was given
     _sample_rate: float = 0.0
     _win: int = config.WIN_SIZE
+    _handle: object = None               # _PlanHandle: the C planner's object (al_plan *), shared by copies of this plan
 
     @property
     def block(self) -> int:
@@ -123,22 +124,20 @@ class BatchPlan:
         return self.n_emitters * self.n_capsules * self.n_partitions
 
     def _c_plan(self):
-        """The C planner's own object for this batch (rebuilt from the specs: the tables above are copies of its arrays)."""
-        if self._specs is None:
-            raise ValueError("this BatchPlan was not made by plan_batch")
-        return _create_c_plan(self._specs, self.n_capsules, self.ir_len, self._sample_rate, self.log2_block, self.hop,
-                              self._win, self.fft_size)
+        """The C planner's own object for this batch (the tables above are copies of its arrays); lives as long as this plan."""
+        if self._handle is None:
+            if self._specs is None:
+                raise ValueError("this BatchPlan was not made by plan_batch")
+            self._handle = _PlanHandle(_create_c_plan(self._specs, self.n_capsules, self.ir_len, self._sample_rate, self.log2_block,
+                                                      self.hop, self._win, self.fft_size))
+        return self._handle.ptr
 
     def _parts(self, fused_moving: bool) -> Optional[np.ndarray]:
         if not len(self.events) or self.n_emitters <= 0:
             return None
-        lib, handle = _lib(), self._c_plan()
-        try:
-            out = np.zeros(self.n_emitters, dtype=np.int32)
-            have = lib.call("al_plan_emitter_parts", handle, 1 if fused_moving else 0, out.ctypes.data)
-            return out if have == 1 else None
-        finally:
-            lib.call("al_plan_destroy", handle)
+        out = np.zeros(self.n_emitters, dtype=np.int32)
+        have = _lib().call("al_plan_emitter_parts", self._c_plan(), 1 if fused_moving else 0, out.ctypes.data)
+        return out if have == 1 else None
 
     def emitter_parts(self) -> Optional[np.ndarray]:
         """al_batch.emitter_parts: per IR column, how many leading partitions can reach a block its event keeps (None: every
@@ -186,13 +185,10 @@ class BatchPlan:
             return [dict(event0=0, n_events=0, stream0=0, n_streams=0, emitter0=0, n_emitters=0, xspec_block0=0, xspec_blocks=0,
                          yspec_block0=0, yspec_blocks=0, max_blocks=0, max_nj=0)]
         lib, handle, out = _lib(), self._c_plan(), []
-        try:
-            for e0 in range(0, n, max(step, 1)):
-                ch = _hip.AlChunk()
-                lib.call("al_plan_chunk", handle, e0, min(step, n - e0), ct.byref(ch))
-                out.append({name: int(getattr(ch, name)) for name, _ in _hip.AlChunk._fields_})
-        finally:
-            lib.call("al_plan_destroy", handle)
+        for e0 in range(0, n, max(step, 1)):
+            ch = _hip.AlChunk()
+            lib.call("al_plan_chunk", handle, e0, min(step, n - e0), ct.byref(ch))
+            out.append({name: int(getattr(ch, name)) for name, _ in _hip.AlChunk._fields_})
         return out
 
     def workspace_bytes(self) -> int:
@@ -206,6 +202,21 @@ def choose_log2_block(ir_len: int, max_clip: int) -> int:
     """Largest block that keeps two workgroups resident per CU (B = 8192: 68 KiB of LDS each),
     shrunk for short inputs so the zero padding of the last block stays small (al_choose_log2_block)."""
     return int(_lib().call("al_choose_log2_block", int(ir_len), int(max_clip)))
+
+
+class _PlanHandle:
+    """Owner of one ``al_plan *``: destroyed with the last BatchPlan that refers to it."""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib().call("al_plan_destroy", self.ptr)
+        except Exception:  # noqa: BLE001 -- interpreter shutdown
+            pass
+        self.ptr = None
 
 
 def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size):
@@ -233,20 +244,19 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
         raise ValueError(f"log2_block must be in [{MIN_LOG2_BLOCK}, {MAX_LOG2_BLOCK}]")
     specs = list(specs)
     lib = _lib()
-    handle = _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size)
-    try:
-        info = _hip.AlPlanInfo()
-        lib.call("al_plan_get_info", handle, ct.byref(info))
-        events = _copy(lib.call("al_plan_events", handle), info.n_events, EVENT_DTYPE)
-        streams = _copy(lib.call("al_plan_streams", handle), info.n_streams, STREAM_DTYPE)
-        wtab = _copy(lib.call("al_plan_wtab", handle), info.wtab_floats, np.float32)
-        offsets = _copy(lib.call("al_plan_audio_offsets", handle), info.n_events, np.int64)
-    finally:
-        lib.call("al_plan_destroy", handle)
+    owner = _PlanHandle(_create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size))
+    handle = owner.ptr
+    info = _hip.AlPlanInfo()
+    lib.call("al_plan_get_info", handle, ct.byref(info))
+    events = _copy(lib.call("al_plan_events", handle), info.n_events, EVENT_DTYPE)
+    streams = _copy(lib.call("al_plan_streams", handle), info.n_streams, STREAM_DTYPE)
+    wtab = _copy(lib.call("al_plan_wtab", handle), info.wtab_floats, np.float32)
+    offsets = _copy(lib.call("al_plan_audio_offsets", handle), info.n_events, np.int64)
     return BatchPlan(log2_block=info.log2_block, n_capsules=n_capsules, ir_len=ir_len, n_emitters=info.n_emitters,
                      events=events, streams=streams, wtab=wtab, audio_offsets=offsets, audio_floats=int(info.audio_floats),
                      spatial_floats=int(info.spatial_floats), xspec_blocks=int(info.xspec_blocks), yspec_blocks=int(info.yspec_blocks),
-                     n_partials=int(info.n_partials), hop=hop, fft_size=fft_size, _specs=specs, _sample_rate=float(sample_rate), _win=win)
+                     n_partials=int(info.n_partials), hop=hop, fft_size=fft_size, _specs=specs, _sample_rate=float(sample_rate), _win=win,
+                     _handle=owner)
 
 
 # ----------------------------------------------------------------------------- mixdown

@@ -401,11 +401,7 @@ def test_c_planner_tables_equal_the_numpy_planner(seed):
         assert _same_optional(pa, pb)
         assert _same_optional(a.fused_moving_parts(pa), b.fused_moving_parts(pb))
         assert a.workspace_bytes() == b.workspace_bytes() and a.max_nj_sliding() == b.max_nj_sliding()
-        handle = a._c_plan()
-        try:
-            assert _hip.get_library().call("al_workspace_bytes", handle) == b.workspace_bytes()
-        finally:
-            _hip.get_library().call("al_plan_destroy", handle)
+        assert _hip.get_library().call("al_workspace_bytes", a._c_plan()) == b.workspace_bytes()   # the plan owns its handle
 
 
 def test_c_planner_mixdown_and_weights_equal_the_numpy_planner():

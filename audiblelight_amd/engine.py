@@ -691,6 +691,13 @@ class PreparedMix:
         self.renderer, self.mix, self.desc, self.scene, self.ambience, self.keep = renderer, mix, desc, scene, ambience, keep
         self.zero_first = zero_first
 
+    def retarget(self, scene) -> "PreparedMix":
+        """The same mixdown (same device tables, same inputs) writing into another (C * T) float32 device buffer: a batch of
+        scenes that reuses one set of resident inputs gives every scene its own output without a device-to-device copy."""
+        desc = type(self.desc).from_buffer_copy(self.desc)   # a ctypes structure copied by value
+        desc.scene = self.renderer.mem.ptr(scene)
+        return PreparedMix(self.renderer, self.mix, desc, scene, self.ambience, self.keep, self.zero_first)
+
     def run(self):
         mem, lib = self.renderer.mem, self.renderer.lib
         stream = mem.stream()

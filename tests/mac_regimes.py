@@ -122,7 +122,7 @@ def is_fused(batch, chunk=0):
 
 
 def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None, expect_split=None,
-                    zero_block=True):
+                    zero_block=True, expect_quad=None):
     """``expect_fused``: None = whatever the library picks (B = 8192: al_mac_synthesis, csrc/al_fused.h), True / False =
     assert it (callers force the unfused kernels with AL_FUSED=0 so that their dispatch branches stay pinned too)."""
     B = 1 << log2_block
@@ -145,6 +145,9 @@ def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0
     assert got_code == code and moving == 0, (got_code, moving)
     if expect_split is not None:
         assert is_split(batch) == expect_split
+    if expect_quad is not None:
+        from audiblelight_amd import _hip
+        assert bool(batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA) == expect_quad
     if expect_fused is not None:
         assert is_fused(batch) == expect_fused
         assert ("al_mac_synthesis" in batch.stage_names()) == expect_fused

@@ -168,6 +168,19 @@ def test_default_layout_per_block_size(gpu, monkeypatch):
         assert mr.is_split(batch) == (lb == 13)
 
 
+def test_quad_layout_alone(gpu, monkeypatch):
+    """The quad slot maps of the split kernels (QuadSlots, csrc/al_fft.h; AL_QUAD=1) WITHOUT the fused kernel: static events through
+    the capsule loop at cfg2's regime and moving events through k_spectral_mac_moving over stored spectra in that layout (the IR,
+    signal and output spectra all permuted the same way; the accumulate must not notice), every row against the oracle."""
+    monkeypatch.setenv("AL_QUAD", "1")
+    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
+    res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=3, E=2, expect_fused=False, expect_split=True, expect_quad=True)
+    assert res.plan.n_partitions == 12
+    monkeypatch.setenv("AL_TRIM_PARTITIONS", "1")
+    res = mr.run_moving_case(gpu, 13, 11.72, n_irs=24, k_mult=30.1, expect_moving=612, C=3, E=2)
+    assert res.plan.log2_block == 13
+
+
 def test_cfg3_regime_all_rows(gpu):
     """cfg3's own regime: B = 8192, P = 12 partitions (2 s RIR), 32 IRs per event, 7.75 s clips; 2 events x 4 capsules,
     every row against the oracle (the full config differs only in the event / capsule counts)."""

@@ -77,7 +77,7 @@ def test_emu_quad_layout_alone(emu, monkeypatch):
     through the capsule loop, moving ones through k_spectral_mac_moving over stored spectra in that layout."""
     monkeypatch.setenv("AL_FUSED_MOVING", "0")
     monkeypatch.setenv("AL_QUAD", "1")
-    mr.run_static_case(emu, 13, 3120301, 6.5, 2.5, C=2, E=1, expect_split=True)
+    mr.run_static_case(emu, 13, 3120301, 6.5, 2.5, C=2, E=1, expect_split=True, expect_quad=True)
 
 
 def test_emu_fused_static_kernel(emu, monkeypatch):

@@ -65,19 +65,34 @@ def check_scene_row(gpu, planning, sc, pl, res, scales, c, ambience=()):
     return got
 
 
-def test_cfg3_full_size_moving_sources(gpu):
-    """BASELINE configs[2]: 16 moving events x 32 waypoint IRs, 32 capsules, 2 s RIRs, 7.75 s clips @ 48 kHz (6.3 GB of IRs)."""
-    from audiblelight_amd import plan as planning, synthetic
+_CFG3 = {}
+
+
+def _cfg3_scene():
+    """The full-size cfg3 scene, drawn once for both parametrisations (6.3 GB of host draws take 20 s)."""
+    from audiblelight_amd import synthetic
+
+    if "scene" not in _CFG3:
+        _CFG3["scene"] = synthetic.make_scene("cfg3")
+    return _CFG3["scene"]
+
+
+@pytest.mark.parametrize("fused", ["0", "1"], ids=["stored_spectra", "fused_moving_kernel"])
+def test_cfg3_full_size_moving_sources(gpu, monkeypatch, fused):
+    """BASELINE configs[2]: 16 moving events x 32 waypoint IRs, 32 capsules, 2 s RIRs, 7.75 s clips @ 48 kHz (6.3 GB of IRs);
+    through the default path over stored IR spectra and through k_moving_fused (AL_FUSED_MOVING=1)."""
+    from audiblelight_amd import plan as planning
     from tests import mac_regimes as mr
 
-    sc = synthetic.make_scene("cfg3")
+    monkeypatch.setenv("AL_FUSED_MOVING", fused)
+    sc = _cfg3_scene()
     assert sc.irs.shape == (32, 16 * 32, 96000) and len(sc.clips) == 16 and len(sc.clips[0]) == 372000
     pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)
     assert pl.log2_block == 13 and pl.n_partitions == 12 and int(pl.events["n_blocks"].max()) == 46
     assert all(int(r) == 1 for r in pl.events["reserved"])
     batch = gpu.prepare(pl, sc.clips, sc.irs)
     moving_code = mr.mac_codes(gpu, batch)[1]
-    assert moving_code in mr.MOVING_CODES + mr.FUSED_MOVING_CODES, moving_code
+    assert moving_code == (10508 if fused == "1" else 612), moving_code
     res = batch.run()
     scales = check_level_invariant(sc, res)
     gains = np.asarray(gpu.mem.download(res.emitter_gain))[: 16 * 32].astype(np.float64)

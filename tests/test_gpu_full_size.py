@@ -114,6 +114,7 @@ def test_cfg5_full_size_64ch_ambience_folded_fx(gpu):
     from audiblelight_amd import ambience as amb, plan as planning, synthetic
     from audiblelight_amd.synthesize import _ambience_on_device
 
+    _CFG3.clear()            # the 6.3 GB cfg3 scene is no longer needed
     sc = synthetic.make_scene("cfg5")
     assert sc.irs.shape == (64, 128, 192000) and len(sc.gain_db) == 128 and sc.duration == 60.0
     pl = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr)

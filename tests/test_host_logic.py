@@ -440,3 +440,22 @@ def test_c_planner_refuses_what_the_reference_refuses():
         planning.plan_batch([planning.EventSpec(0, 1, 1.0)], 1, 10, 8000)
     with pytest.raises(ValueError, match="moving events need Event.duration"):
         planning.plan_batch([planning.EventSpec(9000, 3, 1.0, is_moving=True)], 1, 10, 8000)
+
+
+def test_c_planner_edge_cases():
+    """Empty batches, a scene without events, chunk ranges outside the plan, an event whose slot is empty after rounding."""
+    lib = _hip.get_library()
+    empty = planning.plan_batch([], 3, 1000, 8000)
+    assert len(empty.events) == 0 and empty.n_emitters == 0 and empty.n_partitions == 0 and empty.workspace_bytes() > 0
+    assert empty.emitter_parts() is None and empty.fused_moving_parts(None) is None and empty.chunks(2)[0]["n_events"] == 0
+    pl = planning.plan_batch([planning.EventSpec(3000, 1, 5.0), planning.EventSpec(2000, 0, 5.0, emitter0=1)], 2, 500, 8000, log2_block=10)
+    ch = _hip.AlChunk()
+    with pytest.raises(_hip.HipError, match="bad chunk range"):
+        lib.call("al_plan_chunk", pl._c_plan(), 1, 5, ct.byref(ch))
+    lib.call("al_plan_chunk", pl._c_plan(), 1, 1, ct.byref(ch))          # a chunk of one tiled event: no spectra of its own
+    assert (ch.n_emitters, ch.xspec_blocks, ch.yspec_blocks, ch.n_streams, ch.max_blocks) == (0, 0, 0, 1, 2)
+    mix = planning.plan_mixdown([], [], [], [], [], [], 1.0, 8000, 2)
+    assert mix.n_samples == 8000 and mix.n_tiles == 2 and list(mix.tile_ptr) == [0, 0, 0] and mix.skipped == []
+    mix = planning.plan_mixdown([0.99999, 0.5], [1.5, 0.50001], [4000, 10], [2, 2], [0, 8000], [0, 1], 1.0, 8000, 2)
+    assert mix.skipped == [0, 1] and list(mix.tile_ptr) == [0, 0, 0]   # both slots are empty after rounding (synthesize.py:364-370)
+    assert lib.call("al_choose_log2_block", 96000, 192000) == 13 and lib.call("al_stft_frame_count", 9000, 128) == 73

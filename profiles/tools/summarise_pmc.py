@@ -17,7 +17,7 @@ from bench import source_hash  # noqa: E402  (hash of the kernel sources the pas
 
 NAMES = {"k_forward_spectra": "al_forward_spectra", "k_ir_spectra": "al_ir_spectra", "k_emitter_gains": "al_emitter_gains",
          "k_signal_spectra": "al_signal_spectra",
-         "k_spectral_mac": "al_spectral_mac", "k_block_synthesis": "al_block_synthesis", "k_event_levels": "al_event_levels",
+         "k_spectral_mac": "al_spectral_mac", "k_moving_fused": "al_spectral_mac", "k_block_synthesis": "al_block_synthesis", "k_event_levels": "al_event_levels",
          "k_mixdown": "al_mixdown"}
 
 

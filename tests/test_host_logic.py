@@ -225,6 +225,15 @@ def test_bench_eight_ranks_scene_batch_index_arithmetic():
     assert weak8["gather"]["validated_against_local_rerender"] == {"1": True, "7": True}
     assert weak8["config"]["step_calls"] == one["config"]["step_calls"] and one["n_gpus"] == 1
     assert weak8["config"]["workload"] == one["config"]["workload"]
+    # SURVEY 8e row 2 at eight ranks: one cfg2-shaped scene (32 capsules, shrunk lengths), four capsule rows per rank, the two
+    # all-reduces inside the step, rows gathered and compared with rank 0's render of the whole scene
+    caps = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--repeats", "1",
+                           "--config", "cfg2", "--scale", "0.02", "--shard", "capsules", "--cpu-events", "0", "--cpu-workers", "0"],
+                          env=env, capture_output=True, text=True, timeout=900)
+    assert caps.returncode == 0, caps.stderr[-3000:]
+    out = json.loads([ln for ln in caps.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["n_gpus"] == 8 and out["config"]["capsules_this_rank"] == 4 and out["gather"]["rows_total"] == 32
+    assert out["gather"]["within_tolerance"] and out["gather"]["ranks_seen"] == list(range(8))
 
 
 def test_header_is_plain_c_and_the_c_host_links():

@@ -66,6 +66,16 @@ __device__ __forceinline__ void stream_store(float4 *p, const float4 &v) {
   *p = v;
 }
 template <int SITE>
+__device__ __forceinline__ void stream_store(float *p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr ((AL_NT & SITE) != 0) {
+    __builtin_nontemporal_store(v, p);
+    return;
+  }
+#endif
+  *p = v;
+}
+template <int SITE>
 __device__ __forceinline__ float2 stream_load(const float2 *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr ((AL_NT & SITE) != 0) {

@@ -451,7 +451,7 @@ struct QuadSlots {
 // Spectrum layout: out[0] = (X[0], X[M]) (both real), out[k] = X[k] for 0 < k < M.
 // The transform result lives in v[m] = Z[tid + T*m]; only the mirrored half (Z[M-k], owned by thread T-tid) goes
 // through LDS.
-template <class G, class L = PlainSlots>
+template <class G, class L = PlainSlots, bool LDS_ONLY = false>
 __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], float2 *s, float2 w0, int tid,
                                                        float2 *__restrict__ out) {
   constexpr int M = G::M, T = G::T, E = G::E, H = G::H;
@@ -459,7 +459,7 @@ __device__ __forceinline__ void real_unpack_store_regs(const float2 (&v)[G::E], 
   float2 *own = s + G::pad(tid);
 #pragma unroll
   for (int m = H; m < E; ++m) own[G::pad(T * m)] = v[m];
-  __syncthreads();
+  block_barrier<LDS_ONLY>();
 #pragma unroll
   for (int m = 0; m < H; ++m) {
     const int k = tid + T * m;

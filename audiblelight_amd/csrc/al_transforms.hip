@@ -216,6 +216,7 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
 }  // namespace al
 #include "al_split.h"
 #include "al_quad.h"
+#include "al_quad16.h"
 namespace al {
 
 // ------------------------------------------------------------------ launchers
@@ -234,6 +235,8 @@ namespace al {
     }                                                                                                                   \
   } while (0)
 static bool use_split(const al_batch *b) { return (b->flags & AL_FLAG_SPLIT_SPECTRA) && b->log2_block >= 11; }
+// B = 16384 in four 4096-point tiles (al_quad16.h): the layout of a block IS the quad layout, so the flag selects the kernels
+static bool use_quad16(const al_batch *b) { return use_split(b) && (b->flags & AL_FLAG_QUAD_SPECTRA) && b->log2_block == 14; }
 
 #define AL_DISPATCH_GEOM(b, KERNEL, GRID, ...)                                                                        \
   do {                                                                                                                \
@@ -255,6 +258,10 @@ static bool use_split(const al_batch *b) { return (b->flags & AL_FLAG_SPLIT_SPEC
   } while (0)
 
 hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
+  if (use_quad16(b)) {
+    hipLaunchKernelGGL(k_ir_spectra_quad16, dim3(quad16_runs(b), b->n_capsules, b->n_emitters), dim3(Quad16::T), 0, stream, *b);
+    return hipGetLastError();
+  }
   if (use_split(b)) {
     const dim3 grid(b->n_partitions, b->n_capsules, b->n_emitters);
     AL_DISPATCH_SPLIT(b, k_ir_spectra_split, grid, *b);
@@ -272,7 +279,13 @@ hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream) {
   if (use_split(b) && have_ir && have_sig) {
     const int64_t n_sig = (int64_t)b->max_nj * b->n_streams;
     const int64_t n_ir = (int64_t)b->n_partitions * b->n_capsules * b->n_emitters;
-    if (n_sig + n_ir <= 0x7fffffff) {
+    if (use_quad16(b)) {   // a workgroup per signal window and per run of IR partitions
+      const int64_t n_run = (int64_t)quad16_runs(b) * b->n_capsules * b->n_emitters;
+      if (n_sig + n_run <= 0x7fffffff) {
+        hipLaunchKernelGGL(k_forward_spectra_quad16, dim3((unsigned)(n_sig + n_run)), dim3(Quad16::T), 0, stream, *b, (int)n_sig, quad16_runs(b));
+        return hipGetLastError();
+      }
+    } else if (n_sig + n_ir <= 0x7fffffff) {
       const dim3 grid((unsigned)(n_sig + n_ir));
       AL_DISPATCH_SPLIT(b, k_forward_spectra_split, grid, *b, (int)n_sig);
       return hipGetLastError();
@@ -286,6 +299,10 @@ hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream) {
 
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream) {
   const dim3 grid(b->max_nj, b->n_streams);
+  if (use_quad16(b)) {
+    hipLaunchKernelGGL(k_signal_spectra_quad16, grid, dim3(Quad16::T), 0, stream, *b);
+    return hipGetLastError();
+  }
   if (use_split(b)) {
     AL_DISPATCH_SPLIT(b, k_signal_spectra_split, grid, *b);
     return hipGetLastError();
@@ -313,6 +330,10 @@ hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream) {
 }
 
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream) {
+  if (use_quad16(b)) {
+    hipLaunchKernelGGL(k_block_synthesis_quad16, dim3(b->max_blocks, b->n_capsules, b->n_events), dim3(Quad16::T), 0, stream, *b);
+    return hipGetLastError();
+  }
   if (use_split(b)) {
     const dim3 grid(b->max_blocks, b->n_capsules, b->n_events);
     AL_DISPATCH_SPLIT(b, k_block_synthesis_split, grid, *b);

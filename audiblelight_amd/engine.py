@@ -495,13 +495,18 @@ class Renderer:
         # Split-layout transforms (csrc/al_split.h): every window as two half-size FFTs.  Default at B = 8192, where it is
         # 5 % faster per scene (profiles/r02_split.txt); slower at B = 4096 / 16384.  AL_SPLIT=0 / 1 forces it off / on.
         fused = os.environ.get("AL_FUSED", "0") == "1"
-        want_split = os.environ.get("AL_SPLIT", "1" if plan.log2_block == 13 and not fused else "0") == "1"
+        # B = 16384: four 4096-point transforms per window (csrc/al_quad16.h), the only shape of transform that stays on the HBM
+        # line there; AL_QUAD16=0 goes back to the one- / two-transform kernels of rounds 1-2.
+        quad16 = plan.log2_block == 14 and not fused and os.environ.get("AL_QUAD16", "1") == "1"
+        want_split = os.environ.get("AL_SPLIT", "1" if (plan.log2_block == 13 and not fused) or quad16 else "0") == "1"
         if want_split and plan.log2_block >= 11:
             for desc in descs:
                 desc.flags |= _hip.FLAG_SPLIT_SPECTRA
                 if fuse_moving:
                     desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
                 elif plan.log2_block == 13 and os.environ.get("AL_QUAD", "0") == "1":   # A/B + test switch: the quad layout alone
+                    desc.flags |= _hip.FLAG_QUAD_SPECTRA
+                elif quad16:
                     desc.flags |= _hip.FLAG_QUAD_SPECTRA
         # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes
         # the Y round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).

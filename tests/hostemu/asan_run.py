@@ -91,4 +91,18 @@ for n_irs, k_mult in ((6, 7.3), (4, 6.1)):
     res.check_finite()
     print("asan run ok: fused moving accumulate, code", m_code.value, float(np.abs(res.spatial_audio(0)).sum()))
 del os.environ["AL_FUSED_MOVING"]
+# the quad-tile transforms at B = 16384 (csrc/al_quad16.h): a run of five IR partitions with a ragged last one (the prefetch
+# hand-over), interior and edge signal windows, the rolled general signal path (moving event), the four-tile inverse
+B = 16384
+La, Lir = int(4.4 * B), int(4.6 * B)
+clips = [rng.standard_normal(La).astype(np.float32), rng.standard_normal(int(2.2 * B)).astype(np.float32)]
+irs = (rng.standard_normal((2, 1 + 3, Lir)) * np.exp(-np.arange(Lir) / (Lir / 5.0))).astype(np.float32)
+specs = [planning.EventSpec(n_samples=La, n_emitters=1, snr=10.0, emitter0=0),
+         planning.EventSpec(n_samples=len(clips[1]), n_emitters=3, snr=12.0, emitter0=1, is_moving=True, duration=len(clips[1]) / 48000)]
+pl = planning.plan_batch(specs, 2, Lir, 48000, log2_block=14)
+batch = r.prepare(pl, clips, irs)
+assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA
+res = batch.run()
+res.check_finite()
+print("asan run ok: quad-tile transforms at B = 16384", float(np.abs(res.spatial_audio(0)).sum()))
 print("asan run ok: round-4 kernels")

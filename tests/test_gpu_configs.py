@@ -114,6 +114,16 @@ def test_cfg5_regime_all_rows(gpu):
     for i in range(2):
         mr.check_event_rows(res, i, want_events[i])
     del res, batch
+    # ... and the regime the planner picks for the FULL batch of 128 such events (tests/test_gpu_full_size.py): B = 16384 through the
+    # quad-tile transforms (csrc/al_quad16.h), 12 partitions in the capsule loop's register tile
+    pl14 = planning.plan_batch(sc.specs, 64, sc.ir_len, sc.sr, log2_block=14)
+    batch = gpu.prepare(pl14, sc.sources(), sc.irs)
+    assert pl14.n_partitions == 12 and mr.mac_codes(gpu, batch) == (3121202, 0) and mr.is_split(batch)
+    res = batch.run()
+    res.check_finite()
+    for i in range(2):
+        mr.check_event_rows(res, i, want_events[i])
+    del res, batch
     syn.set_renderer(gpu)
     try:
         scene = core.Scene(sc.duration, core.StaticIRState({"em64": sc.irs}), sample_rate=sc.sr, ref_db=-65)

@@ -221,6 +221,27 @@ def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
     mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True, expect_split=False)
 
 
+def test_quad16_transforms_all_rows(gpu, monkeypatch):
+    """B = 16384 as four 4096-point tiles (csrc/al_quad16.h): k_forward_spectra_quad16 / k_block_synthesis_quad16 around the
+    unchanged accumulate.  cfg5's regime (12 partitions in three runs of four, 12 blocks), a short batch with a ragged last
+    partition and edge windows, a moving event (the rolled general signal path, sliding-window accumulate), every row against
+    the oracle; then the separate IR / signal launches (al_ir_spectra + al_signal_spectra) against the merged one, bit for bit."""
+    monkeypatch.delenv("AL_QUAD16", raising=False)
+    res = mr.run_static_case(gpu, 14, 3121202, 192000 / 16384, 192000 / 16384, C=3, E=2, expect_split=True, expect_quad=True)
+    assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 12
+    mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=True, expect_quad=True)
+    mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)
+    mr.run_moving_case(gpu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
+    mr.run_separate_forward_launches(gpu, 14)
+
+
+def test_quad16_random_batches(gpu, monkeypatch):
+    """Seeded random batches (static / moving / zero-emitter events mixed) at B = 16384 through the quad-tile transforms."""
+    monkeypatch.delenv("AL_QUAD16", raising=False)
+    for seed in (3, 11, 29):
+        mr.run_random_batch(gpu, seed, log2_block=14)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_random_shapes_over_the_whole_dispatch_space(gpu, monkeypatch, seed):
     """Seeded random batches: 1..26 partitions x clips of up to 60 blocks x static / moving / zero-emitter events mixed in one

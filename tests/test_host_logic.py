@@ -346,6 +346,31 @@ def test_planner_invariants_on_random_scenes():
     check()
 
 
+def test_planner_block_size_rule_for_long_irs():
+    """al_plan_create picks B = 16384 (csrc/al_quad16.h) only where it was measured to pay (profiles/r04s_quad16_ir_sweep*.txt): all
+    events static, 17..24 partitions of 8192, at least 100 000 (capsule, block) rows; the numpy planner of rounds 1-3 with the same
+    rule agrees table for table."""
+    from tests import plan_reference as ref
+
+    def both(n_events, C, ir_len, n_samples=192000, moving_at=None):
+        kw = [dict(n_samples=n_samples, n_emitters=1, snr=5.0, emitter0=e) for e in range(n_events)]
+        if moving_at is not None:
+            kw[moving_at] = dict(n_samples=n_samples, n_emitters=4, snr=5.0, emitter0=n_events, is_moving=True, duration=n_samples / 48000.0)
+        a = planning.plan_batch([planning.EventSpec(**k) for k in kw], C, ir_len, 48000.0)
+        b = ref.plan_batch([ref.EventSpec(**k) for k in kw], C, ir_len, 48000.0)
+        assert a.log2_block == b.log2_block and a.events.tobytes() == b.events.tobytes() and a.streams.tobytes() == b.streams.tobytes()
+        return a
+
+    assert (both(128, 64, 192000).log2_block, both(128, 64, 192000).n_partitions) == (14, 12)       # BASELINE configs[4]
+    assert both(70, 64, 8192 * 16 + 1).log2_block == 14                                             # 17 partitions, 107 520 rows
+    assert both(65, 64, 8192 * 16 + 1).log2_block == 13                                             # 99 840 rows
+    assert both(128, 64, 8192 * 16).log2_block == 13                                                # 16 partitions
+    assert both(128, 64, 8192 * 24 + 1).log2_block == 13                                            # 25 partitions
+    assert both(32, 32, 192000).log2_block == 13                                                    # small batch
+    assert both(128, 64, 192000, moving_at=5).log2_block == 13                                      # a moving event: not measured
+    assert planning.plan_batch([planning.EventSpec(192000, 1, 5.0)] * 128, 64, 192000, 48000.0, log2_block=13).log2_block == 13   # the caller's choice stands
+
+
 def test_every_accumulate_instantiation_is_named_by_a_gpu_test():
     """Every k_spectral_mac* kernel the library holds (nm -C) must be the expected instantiation of some -m gpu parity test
     (tests/mac_regimes.py: STATIC_CASES, STATIC_LOOP_CASES, MOVING_CODES, EXTRA_STATIC_CODES, each asserted through

@@ -80,6 +80,19 @@ def test_emu_quad_layout_alone(emu, monkeypatch):
     mr.run_static_case(emu, 13, 3120301, 6.5, 2.5, C=2, E=1, expect_split=True, expect_quad=True)
 
 
+def test_emu_quad16_transforms(emu, monkeypatch):
+    """csrc/al_quad16.h under emulation (B = 16384 as four 4096-point tiles): a run of three IR partitions with a ragged last one
+    (the prefetch hand-over between partitions), interior and edge signal windows, the rolled general signal path with cross-fade
+    envelopes (moving event), the inverse that assembles a block from the four tiles; every row against the oracle.  And with
+    AL_QUAD16=0 the one-transform kernels of round 1 still serve B = 16384."""
+    monkeypatch.delenv("AL_QUAD16", raising=False)
+    mr.run_static_case(emu, 14, 3120301, 3.5, 2.5, C=2, E=2, expect_split=True, expect_quad=True)
+    mr.run_moving_case(emu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
+    mr.run_separate_forward_launches(emu, 14)
+    monkeypatch.setenv("AL_QUAD16", "0")
+    mr.run_static_case(emu, 14, 3120201, 2.2, 1.5, C=1, E=1, expect_split=False, expect_quad=False)
+
+
 def test_emu_fused_static_kernel(emu, monkeypatch):
     """k_mac_synthesis (B = 8192) under emulation: three k-tiles with a ragged last one, a partly empty partition tile,
     the bin-0 fix-up, the LDS hand-over into the transform layout; every row against the oracle."""

@@ -1,11 +1,12 @@
 // Quad-tile transforms at B = 16384 (included by al_transforms.hip).
 //
-// Why: the accumulate prefers few, long partitions -- for IRs of 2.05-4.1 s (13..24 partitions at B = 8192, e.g. cfg5) only
-// B = 16384 brings it back into the capsule loop's register tile (P <= 12, the signal window in registers across capsules).
-// But at B = 16384 the transforms of rounds 1-3 fall off their line: one 16384-point transform per window needs 139 KB of LDS
-// (one workgroup per CU), two 8192-point ones (split layout) 68 KB each (two).  The 4096-point transform (35 KB of LDS,
-// three workgroups per CU) is the one that runs on the HBM line.  So a window's spectrum at B = 16384 is made of FOUR
-// independent 4096-point transforms: the quad tiles of csrc/al_quad.h, here as the NATIVE layout of the block (no slot map):
+// Why: the accumulate prefers few, long partitions -- for IRs of 2.8-4.1 s (17..24 partitions at B = 8192, e.g. cfg5) only
+// B = 16384 brings it back into the capsule loop's register tile (P <= 12, the signal window in registers across capsules:
+// 5.2 instead of 4.1 TB/s on cfg5's accumulate).  But at B = 16384 the transforms of rounds 1-3 fall off their line: one
+// 16384-point transform per window needs 139 KB of LDS (one workgroup per CU), two 8192-point ones (split layout) 68 KB each
+// (two); cfg5 at B = 16384 through them: 17.0 ms per scene against 15.0 at B = 8192.  The 4096-point transform (35 KB of LDS,
+// three passes of radix 16) is the one this chip runs well.  So a window's spectrum at B = 16384 is made of FOUR independent
+// 4096-point transforms: the quad tiles of csrc/al_quad.h, here as the NATIVE layout of the block (no slot map):
 //   slots [0, Q)   T0 = W[4i]   = rFFT_{2Q}(a)[i],  a[t] = s[t] + s[t + 2Q]          (slot 0 packs W[0] and W[B])
 //   slots [Q, 2Q)  T1 = W[8i+2] = FFT_Q( ((s0 - s2) - i (s1 - s3)) w^2 )
 //   slots [2Q,3Q)  T2 = W[8i+1] = FFT_Q( ((d0 - i d2) + c8 (d1 - i d3)) w   )
@@ -15,6 +16,14 @@
 // with dd[t] = s[t] - s[t + 2Q]; v[n], v[n + Q] from T2 +- T3 with v[m] = (d[m] - i d[m + 2Q]) w_m; then the alias-free half
 // w2 = (s - d) / 2.  (Checked in numpy before it was written; every row against the oracle in tests/test_gpu_mac_regimes.py.)
 // The accumulate is element-wise on slots and only treats slot 0 specially: unchanged.
+//
+// Shape of the kernels (what was measured on the way: profiles/r04s_quad16_ab_v*.txt):
+//  - a window's samples are read ONCE and the inputs of all four transforms held in registers (128), the inverse keeps 64 partial
+//    sums across its four transforms: two waves per SIMD (256 registers), not the three of the 8192-point split kernels;
+//  - what the lower occupancy would expose is covered inside the workgroup: every barrier of the transforms waits for LDS traffic
+//    only (block_barrier), so stores and the requests for the NEXT tile / IR partition stay in flight across them;
+//  - both kernels issue 63-72 % of the VALU instructions the chip can (SQ_INSTS_VALU, profiles/r04t_valu_floor.txt) -- like the
+//    8192-point split kernels they are bound by instruction issue + the LDS exchanges between passes, not by HBM.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -72,9 +81,9 @@ __device__ __forceinline__ void quad16_fft(float2 (&v)[16], float2 *s, FftTwiddl
 // ------------------------------------------------------------------ forward: the four tiles of one window
 // sk[k][i] = s[n + k Q], dk[k][i] = d[n + k Q] at n = tid + 256 i (an IR partition: the same array twice).  The samples are read
 // ONCE (a workgroup that comes back for them a transform later finds most of them gone from the L2: +20 % on the kernel,
-// profiles/r04s_quad16_ab.txt), so the inputs of all four transforms are made here and held: 128 registers, which is why these
-// kernels are compiled for two waves per SIMD.  `prefetch(0)` is called once tiles 2 and 3 are stored, `prefetch(1)` after tile 1: the caller requests one half of its next window
-// at each, into the registers that have become free.
+// profiles/r04s_quad16_ab_v1_reread.txt), so the inputs of all four transforms are made here and held: 128 registers, which is why these
+// kernels are compiled for two waves per SIMD.  `prefetch(0)` is called once tiles 2 and 3 are stored, `prefetch(1)` after tile 1:
+// the caller requests one half of its next window at each, into the registers that have become free.
 template <class Prefetch>
 __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], const float (&dk)[4][16], float2 *__restrict__ out, float2 *s,
                                                      FftTwiddles<Quad16::G> &tw, float2 wt, int tid, Prefetch &&prefetch) {

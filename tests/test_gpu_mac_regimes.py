@@ -27,7 +27,7 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
     static events (they are the default for more than 12 partitions and for multi-emitter events)."""
     monkeypatch.setenv("AL_STATIC_MAC", "0")
     monkeypatch.delenv("AL_FUSED", raising=False)
-    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block == 13))
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block >= 13))   # 14: csrc/al_quad16.h
 
 
 @pytest.mark.parametrize("log2_block", [10, 13])
@@ -135,6 +135,7 @@ def test_transform_layouts(gpu, monkeypatch, log2_block, split):
     from oracle import synth_oracle as orc
 
     monkeypatch.setenv("AL_SPLIT", split)
+    monkeypatch.setenv("AL_QUAD16", "0")       # B = 16384 here: two 8192-point transforms (the quad tiles have their own tests below)
     B = 1 << log2_block
     rng = np.random.default_rng(40 + log2_block)
     sr, C, L = 48000, 3, int(2.3 * B) + 7
@@ -165,7 +166,7 @@ def test_default_layout_per_block_size(gpu, monkeypatch):
     for lb in (10, 12, 13, 14):
         pl = planning.plan_batch([planning.EventSpec(n_samples=3000, n_emitters=1, snr=5.0)], 2, 500, 48000, log2_block=lb)
         batch = gpu.prepare(pl, [np.zeros(3000, np.float32)], np.zeros((2, 1, 500), np.float32))
-        assert mr.is_split(batch) == (lb == 13)
+        assert mr.is_split(batch) == (lb >= 13)
 
 
 def test_quad_layout_alone(gpu, monkeypatch):
@@ -227,12 +228,14 @@ def test_quad16_transforms_all_rows(gpu, monkeypatch):
     partition and edge windows, a moving event (the rolled general signal path, sliding-window accumulate), every row against
     the oracle; then the separate IR / signal launches (al_ir_spectra + al_signal_spectra) against the merged one, bit for bit."""
     monkeypatch.delenv("AL_QUAD16", raising=False)
-    res = mr.run_static_case(gpu, 14, 3121202, 192000 / 16384, 192000 / 16384, C=3, E=2, expect_split=True, expect_quad=True)
+    res = mr.run_static_case(gpu, 14, 3121201, 192000 / 16384, 192000 / 16384, C=3, E=2, expect_split=True, expect_quad=True)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 12
     mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=True, expect_quad=True)
     mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)
     mr.run_moving_case(gpu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
     mr.run_separate_forward_launches(gpu, 14)
+    monkeypatch.setenv("AL_QUAD16", "0")       # and the one-transform kernels of round 1 still serve B = 16384
+    mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=False, expect_quad=False)
 
 
 def test_quad16_random_batches(gpu, monkeypatch):

@@ -41,32 +41,48 @@ struct Quad16 {
   static constexpr int Q = 4096, B = 16384, T = 256;
 };
 
-// e^{-i pi i / 64}, i < 16: the step of the twist e^{-i pi n / B} between a thread's slots n = tid + 256 i
+// Twists e^{-i pi K n / B}, K = 1, 2, 4, 5, at a thread's slots n = tid + 256 i: the thread's own power (e^{-i pi tid / B})^K, made once per
+// window from ONE table entry, times the compile-time step e^{-i pi K i / 64}
+constexpr double ct_cos_turn(int num, int den) {       // cos(pi num / den), any num >= 0
+  num %= 2 * den;
+  if (num > den) num = 2 * den - num;
+  return 2 * num <= den ? ct_cospi(num, den) : -ct_cospi(den - num, den);
+}
+constexpr double ct_sin_turn(int num, int den) {       // sin(pi num / den), any num >= 0
+  num %= 2 * den;
+  const double sign = num > den ? -1.0 : 1.0;
+  if (num > den) num = 2 * den - num;
+  return sign * (2 * num <= den ? ct_sinpi(num, den) : ct_sinpi(den - num, den));
+}
+template <int K>
 struct Quad16Steps {
   float c[16], s[16];
   constexpr Quad16Steps() : c{}, s{} {
     for (int i = 0; i < 16; ++i) {
-      c[i] = (float)ct_cospi(i, 64);
-      s[i] = (float)ct_sinpi(i, 64);
+      c[i] = (float)ct_cos_turn(K * i, 64);
+      s[i] = (float)ct_sin_turn(K * i, 64);
     }
   }
 };
-
-// e^{-i pi n / B} for n = tid + 256 i from ONE table entry (the block's table has B points) and compile-time steps
-__device__ __forceinline__ float2 quad16_twist(float2 wt, int i) {
-  constexpr Quad16Steps ff{};
-  return cmul(wt, make_float2(ff.c[i], -ff.s[i]));
+template <int K>
+__device__ __forceinline__ float2 quad16_twist(float2 wtk, int i) {
+  constexpr Quad16Steps<K> ff{};
+  return cmul(wtk, make_float2(ff.c[i], -ff.s[i]));
 }
+struct Quad16Twists {            // (e^{-i pi tid / B})^K for K = 1, 2, 5
+  float2 w1, w2, w5;
+  __device__ __forceinline__ explicit Quad16Twists(float2 wt) : w1(wt), w2(cmul(wt, wt)), w5(cmul(cmul(w2, w2), wt)) {}
+};
 
-// Transform inputs of tiles 1..3 at slot n from the four samples x_k = x[n + k Q] of s (tile 1) or d (tiles 2, 3)
+// Transform inputs of tiles 1..3 at slot n from the four samples x_k = x[n + k Q] of s (tile 1) or d (tiles 2, 3); `w` = the twist of
+// the tile at n: e^{-i pi n / B} to the power 2 (tile 1), 1 (tile 2), 5 (tile 3)
 template <int TILE>
 __device__ __forceinline__ float2 quad16_fold(float x0, float x1, float x2, float x3, float2 w) {
   constexpr float R2 = 0.70710678118654752440f;
-  const float2 w2 = cmul(w, w);
-  if constexpr (TILE == 1) return cmul(make_float2(x0 - x2, x3 - x1), w2);
+  if constexpr (TILE == 1) return cmul(make_float2(x0 - x2, x3 - x1), w);
   const float2 p = make_float2(x0, -x2), q = make_float2(R2 * (x1 - x3), -R2 * (x1 + x3));
   if constexpr (TILE == 2) return cmul(cadd(p, q), w);
-  return cmul(csub(p, q), cmul(cmul(w2, w2), w));
+  return cmul(csub(p, q), w);
 }
 
 // One transform of a kernel that runs several: the pass factors are made opaque first, or the fifteen powers per pass derived from
@@ -84,7 +100,7 @@ __device__ __forceinline__ void quad16_fft(float2 (&v)[16], float2 *s, FftTwiddl
 // profiles/r04s_quad16_ab_v1_reread.txt), so the inputs of all four transforms are made here and held: 128 registers, which is why these
 // kernels are compiled for two waves per SIMD.  `prefetch(0)` is called once tiles 2 and 3 are stored, `prefetch(1)` after tile 1:
 // the caller requests one half of its next window at each, into the registers that have become free.
-template <class Prefetch>
+template <bool SAME, class Prefetch>
 __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], const float (&dk)[4][16], float2 *__restrict__ out, float2 *s,
                                                      FftTwiddles<Quad16::G> &tw, float2 wt, int tid, Prefetch &&prefetch) {
   using G = Quad16::G;
@@ -92,22 +108,40 @@ __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], c
   float2 z1[16], z2[16], z3[16];
   float a_lo[16], a_hi[16];          // a[n], a[n + Q] of a[t] = s[t] + s[t + 2Q]
   make_opaque(wt);                   // the twists are made here, per window
+  const Quad16Twists tk(wt);
+  // SAME (an IR partition, s = d = h): each tile's input is made from the 64 samples right before its transform, so that no more
+  // than those 64 are held across a transform; else (a signal window: 64 + 64 samples) all of them now, 96 held across the first.
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const float2 w = quad16_twist(wt, i);
-    z1[i] = quad16_fold<1>(sk[0][i], sk[1][i], sk[2][i], sk[3][i], w);
-    z2[i] = quad16_fold<2>(dk[0][i], dk[1][i], dk[2][i], dk[3][i], w);
-    z3[i] = quad16_fold<3>(dk[0][i], dk[1][i], dk[2][i], dk[3][i], w);
-    a_lo[i] = sk[0][i] + sk[2][i];
-    a_hi[i] = sk[1][i] + sk[3][i];
+    z2[i] = quad16_fold<2>(dk[0][i], dk[1][i], dk[2][i], dk[3][i], quad16_twist<1>(tk.w1, i));
+    if constexpr (!SAME) {
+      z3[i] = quad16_fold<3>(dk[0][i], dk[1][i], dk[2][i], dk[3][i], quad16_twist<5>(tk.w5, i));
+      z1[i] = quad16_fold<1>(sk[0][i], sk[1][i], sk[2][i], sk[3][i], quad16_twist<2>(tk.w2, i));
+      a_lo[i] = sk[0][i] + sk[2][i];
+      a_hi[i] = sk[1][i] + sk[3][i];
+    }
   }
   // every barrier below waits for LDS traffic only (block_barrier): stores and the caller's requests stay in flight across them
   quad16_fft<-1, true>(z2, s, tw, tid);
 #pragma unroll
   for (int i = 0; i < 16; ++i) stream_store<4>(out + 2 * Q + tid + T * i, z2[i]);
+  if constexpr (SAME) {
+    pipeline_fence();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z3[i] = quad16_fold<3>(dk[0][i], dk[1][i], dk[2][i], dk[3][i], quad16_twist<5>(tk.w5, i));
+  }
   quad16_fft<-1, true>(z3, s, tw, tid);
 #pragma unroll
   for (int i = 0; i < 16; ++i) stream_store<4>(out + 3 * Q + tid + T * i, z3[i]);
+  if constexpr (SAME) {
+    pipeline_fence();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      z1[i] = quad16_fold<1>(sk[0][i], sk[1][i], sk[2][i], sk[3][i], quad16_twist<2>(tk.w2, i));
+      a_lo[i] = sk[0][i] + sk[2][i];
+      a_hi[i] = sk[1][i] + sk[3][i];
+    }
+  }
   prefetch(std::integral_constant<int, 0>{});
   pipeline_fence();
   quad16_fft<-1, true>(z1, s, tw, tid);
@@ -190,7 +224,7 @@ __device__ __forceinline__ void ir_spectra_quad16_body(const al_batch &b, float2
     float hn[4][16];
     if (p < p_live) {                                  // workgroup-uniform; else: no kept block hears it, its energy still counts
       float2 *out = reinterpret_cast<float2 *>(b.hspec) + (((int64_t)nz * b.n_capsules + c) * b.n_partitions + p) * B;
-      quad16_forward_tiles(h, h, out, s, tw, wt, tid, [&](auto half_c) { if (p + 1 < p1) request(p + 1, hn, decltype(half_c)::value); });
+      quad16_forward_tiles<true>(h, h, out, s, tw, wt, tid, [&](auto half_c) { if (p + 1 < p1) request(p + 1, hn, decltype(half_c)::value); });
     } else if (p + 1 < p1) {
       request(p + 1, hn, 0);
       request(p + 1, hn, 1);
@@ -242,7 +276,8 @@ __device__ __forceinline__ void signal_tile_quad16(const Quad16Signal &sig, int 
         const float w1 = sig.at(t + Q * k), w2 = sig.at(t + Q * k + B);
         x[k] = TILE == 1 ? w1 + w2 : w1 - w2;
       }
-      v = quad16_fold<TILE>(x[0], x[1], x[2], x[3], table[tid + T * i]);
+      const float2 w = table[tid + T * i], w2 = cmul(w, w);      // e^{-i pi n / B} at n = tid + 256 i, straight from the table
+      v = quad16_fold<TILE>(x[0], x[1], x[2], x[3], TILE == 1 ? w2 : TILE == 2 ? w : cmul(cmul(w2, w2), w));
     }
     s[tid + T * i] = v;
   }
@@ -285,7 +320,7 @@ __device__ __forceinline__ void signal_spectra_quad16_body(const al_batch &b, fl
         sk[k][i] = w1 + w2;
         dk[k][i] = w1 - w2;
       }
-    quad16_forward_tiles(sk, dk, out, s, tw, table[tid], tid, [](auto) {});
+    quad16_forward_tiles<false>(sk, dk, out, s, tw, table[tid], tid, [](auto) {});
   } else {
     const Quad16Signal sig{b.audio + ev.audio_off, b.wtab + (moving ? st.w_off : 0), ev.len, st.w_len, b.hop, gain, moving};
     signal_tile_quad16<0>(sig, t0, table, out, s, tw, tid);
@@ -372,10 +407,10 @@ __global__ __launch_bounds__(256, AL_Q16_WAVES) void k_block_synthesis_quad16(al
       quad16_fft<1, true>(z2, s, tw, tid);
       float2 wl = wt;
       make_opaque(wl);          // the twists are made HERE, not held across the transforms
+      const float2 wl2 = cmul(wl, wl), wl4 = cmul(wl2, wl2);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float2 w = quad16_twist(wl, i), cw = cconj(w);
-        const float2 w2 = cmul(w, w), cw4 = cconj(cmul(w2, w2));
+        const float2 cw = cconj(quad16_twist<1>(wl, i)), cw4 = cconj(quad16_twist<4>(wl4, i));
         const float2 a3 = cmul(z3[i], cw4);
         const float2 v0 = make_float2(z2[i].x + a3.x, z2[i].y + a3.y), v1 = make_float2(z2[i].x - a3.x, z2[i].y - a3.y);   // 2 v[n], 2 v[n+Q]
         const float2 p = cmul(v0, cw);                                           // 2 (d0 - i d2)
@@ -391,10 +426,10 @@ __global__ __launch_bounds__(256, AL_Q16_WAVES) void k_block_synthesis_quad16(al
       quad16_fft<1, true>(z1, s, tw, tid);
       float2 wl = wt;
       make_opaque(wl);
+      const float2 wl2 = cmul(wl, wl);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float2 w = quad16_twist(wl, i);
-        const float2 u = cmul(z1[i], cconj(cmul(w, w)));                       // dd[n] - i dd[n + Q]
+        const float2 u = cmul(z1[i], cconj(quad16_twist<2>(wl2, i)));          // dd[n] - i dd[n + Q]
         const float q4 = 0.25f * inv;                                          // s_k / 2 = (a +- dd) / 4
         acc[0][i] += q4 * u.x; acc[2][i] -= q4 * u.x;
         acc[1][i] -= q4 * u.y; acc[3][i] += q4 * u.y;

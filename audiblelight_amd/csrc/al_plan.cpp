@@ -108,8 +108,8 @@ int al_plan_create(const al_event_spec *specs, int32_t n_events, int32_t n_capsu
     log2_block = al_choose_log2_block(ir_len, longest);
     // B = 16384 (four 4096-point transforms per window, csrc/al_quad16.h) for big batches of static events with 17..24 partitions
     // of 8192: the accumulate is back in the capsule loop's register tile (<= 12 partitions: 5.2 instead of 4.1 TB/s on cfg5), which
-    // pays for the slower transforms from about 100 000 (capsule, block) rows on (profiles/r04s_quad16_ir_sweep*.txt: -5..-7 % per
-    // batch there, +1..+6 % on smaller batches, + everywhere outside 17..24).  Moving events: not measured, so not switched.
+    // pays for the slower transforms from about 100 000 (capsule, block) rows on (profiles/r04u_quad16_ir_sweep_*.txt: -4..-11 % per
+    // batch from there on, -2..+5 % at half that size, slower everywhere outside 17..24).  Moving events: not measured, so not switched.
     const int64_t p13 = ((int64_t)ir_len + 8191) / 8192;
     if (log2_block == 13 && p13 >= 17 && p13 <= 24) {
       int64_t blocks = 0;

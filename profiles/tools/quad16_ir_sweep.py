@@ -14,7 +14,7 @@ rng = np.random.default_rng(0)
 C, E, La = (int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (32, 32, 192000)))
 clips = [rng.standard_normal(La).astype(np.float32) for _ in range(E)]
 specs = [planning.EventSpec(n_samples=La, n_emitters=1, snr=10.0, emitter0=e) for e in range(E)]
-for Lir in (90000, 100000, 115000, 131072, 150000, 172000, 192000, 230000, 300000):
+for Lir in [int(x) for x in os.environ.get("LIRS", "90000 100000 115000 131072 150000 172000 192000 230000 300000").split()]:
     irs = torch.randn((C * E, Lir), device="cuda", dtype=torch.float32)        # drawn on the device, as bench.py does
     irs *= torch.exp(-torch.arange(Lir, device="cuda", dtype=torch.float32) / (Lir / 6.9))[None, :]
     irs = irs.reshape(-1)

@@ -347,7 +347,7 @@ def test_planner_invariants_on_random_scenes():
 
 
 def test_planner_block_size_rule_for_long_irs():
-    """al_plan_create picks B = 16384 (csrc/al_quad16.h) only where it was measured to pay (profiles/r04s_quad16_ir_sweep*.txt): all
+    """al_plan_create picks B = 16384 (csrc/al_quad16.h) only where it was measured to pay (profiles/r04u_quad16_ir_sweep_*.txt): all
     events static, 17..24 partitions of 8192, at least 100 000 (capsule, block) rows; the numpy planner of rounds 1-3 with the same
     rule agrees table for table."""
     from tests import plan_reference as ref

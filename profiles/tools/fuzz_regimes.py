@@ -6,7 +6,7 @@ import collections, os, sys, time
 from concurrent.futures import ProcessPoolExecutor
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, ROOT)
-BLOCKS = (10, 11, 12, 13, 14, 13)     # B = 8192, the production block, twice
+BLOCKS = tuple(int(x) for x in os.environ.get("FUZZ_BLOCKS", "10 11 12 13 14 13").split())     # default: B = 8192, the production block, twice
 
 
 def work(span):

@@ -53,7 +53,11 @@ extern "C" {
                                    kernels are not launched at all (the host knows the event table, the library does not) */
 #define AL_FLAG_QUAD_SPECTRA 256 /* with AL_FLAG_SPLIT_SPECTRA at B = 8192: every half of a spectrum stored as two tiles of B/4 slots,
                                     each a plain B/4-point transform of the folded window (csrc/al_quad.h, QuadSlots in csrc/al_fft.h):
-                                    what lets a workgroup make ITS slice of an IR partition's spectrum from the raw samples */
+                                    what lets a workgroup make ITS slice of an IR partition's spectrum from the raw samples.
+                                    With AL_FLAG_SPLIT_SPECTRA at B = 16384: the four-tile layout of csrc/al_quad16.h (every window as
+                                    four 4096-point transforms) -- set both there: the one-transform kernels are 15-20 % slower
+                                    per scene at that block size.  The planner (al_plan_create) picks B = 16384 by itself only for
+                                    big batches of static events with 17..24 partitions of 8192 */
 #define AL_FLAG_FUSED_MOVING 512 /* with AL_FLAG_QUAD_SPECTRA: sliding-window moving events (al_event.reserved == 1) go through
                                     k_moving_fused, which transforms the IR partitions itself: their spectra are never written.
                                     The caller sets emitter_parts[n] = 0 for the IR columns of those events (the forward kernel

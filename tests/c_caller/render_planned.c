@@ -137,7 +137,8 @@ int main(int argc, char **argv) {
   HIP_OK(hipMemsetAsync((char *)b.hspec + (size_t)h_max * blk, 0, blk, stream));
   HIP_OK(hipMemsetAsync((char *)b.xspec + (size_t)x_max * blk, 0, blk, stream));
   b.hspec_zero_block = (int32_t)h_max, b.xspec_zero_block = (int32_t)x_max;
-  int32_t flags = info.log2_block == 13 ? AL_FLAG_SPLIT_SPECTRA : 0;
+  /* the layouts the transforms are fastest in: split at B = 8192, quad tiles at B = 16384 (include/audiblelight_hip.h) */
+  int32_t flags = info.log2_block == 13 ? AL_FLAG_SPLIT_SPECTRA : info.log2_block == 14 ? (AL_FLAG_SPLIT_SPECTRA | AL_FLAG_QUAD_SPECTRA) : 0;
   int fused = 0;
   if (want_fused && info.log2_block == 13 && info.max_nj_sliding >= 1 && info.max_nj_sliding <= 5) {
     b.flags = flags | AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5;

@@ -55,12 +55,14 @@ PLANNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_caller", "
 
 @pytest.mark.parametrize("log2_block,chunk_events,fused,lir,expect_code", [(10, 0, 0, 2600, 612), (10, 2, 0, 2600, 612),
                                                                               (13, 0, 1, 30_001, 10508), (13, 3, 1, 30_001, 10508),
-                                                                              (13, 0, 0, 30_001, 612)],
-                         ids=["B1024_one_batch", "B1024_chunks_of_2", "B8192_fused_moving", "B8192_fused_moving_chunks_of_3", "B8192_stored_spectra"])
+                                                                              (13, 0, 0, 30_001, 612), (14, 2, 0, 60_001, 612)],
+                         ids=["B1024_one_batch", "B1024_chunks_of_2", "B8192_fused_moving", "B8192_fused_moving_chunks_of_3", "B8192_stored_spectra",
+                              "B16384_quad_tiles_chunks_of_2"])
 def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fused, lir, expect_code):
     """tests/c_caller/render_planned.c: static + moving + tiled events, an ambience and a chunked batch from a C host that
     takes EVERY table from the library's planner (al_plan_create / al_plan_chunk / al_plan_emitter_parts / al_plan_mixdown);
-    every row of every event and of the scene against the oracle.  At B = 8192 the moving events go through k_moving_fused."""
+    every row of every event and of the scene against the oracle.  At B = 8192 the moving events go through k_moving_fused when
+    asked to; at B = 16384 the host sets the quad-tile layout flags (csrc/al_quad16.h)."""
     if not os.path.exists(PLANNED):
         import __graft_entry__
 

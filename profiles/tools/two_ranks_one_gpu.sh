@@ -3,7 +3,7 @@
 # (rank 0 re-renders rank 1's scene with the real kernels and compares bit for bit).  Timings mean nothing (one GPU shared).
 cd $GRAFT_REPO_ROOT
 export AL_DIST_BACKEND=gloo MASTER_ADDR=127.0.0.1 MASTER_PORT=29533 WORLD_SIZE=2 LOCAL_RANK=0
-for MODE in "--config cfg2" "--config cfg4 --total-scenes 6" "--config cfg5 --shard capsules --scale 0.25"; do
+for MODE in "--config cfg2" "--config cfg4 --total-scenes 6" "--config cfg5 --shard capsules --scale 0.25" "--config cfg5 --shard capsules --scale 0.5 --log2-block 14"; do
   TAG=$(echo $MODE | tr -d ' -')
   RANK=1 python bench.py --gpus 2 $MODE --steps 5 --warmup 2 --repeats 2 --cpu-events 0 > gpurun_out/two_rank1_$TAG.txt 2>&1 &
   RANK=0 python bench.py --gpus 2 $MODE --steps 5 --warmup 2 --repeats 2 --cpu-events 0 > gpurun_out/two_rank0_$TAG.txt 2>&1

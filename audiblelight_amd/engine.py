@@ -493,10 +493,10 @@ class Renderer:
             xspec_zero_block=x_blocks, hspec_zero_block=h_blocks, **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
         # Split-layout transforms (csrc/al_split.h): every window as two half-size FFTs.  Default at B = 8192, where it is
-        # 5 % faster per scene (profiles/r02_split.txt); slower at B = 4096 / 16384.  AL_SPLIT=0 / 1 forces it off / on.
+        # 5 % faster per scene (profiles/r02_split.txt); slower at B = 4096 and, as two 8192-point transforms, at 16384.  AL_SPLIT=0 / 1 forces it off / on.
         fused = os.environ.get("AL_FUSED", "0") == "1"
-        # B = 16384: four 4096-point transforms per window (csrc/al_quad16.h), the only shape of transform that stays on the HBM
-        # line there; AL_QUAD16=0 goes back to the one- / two-transform kernels of rounds 1-2.
+        # B = 16384: four 4096-point transforms per window (csrc/al_quad16.h; cfg5 13.9 instead of 17.0 ms per scene);
+        # AL_QUAD16=0 goes back to the one- / two-transform kernels of rounds 1-2.
         quad16 = plan.log2_block == 14 and not fused and os.environ.get("AL_QUAD16", "1") == "1"
         want_split = os.environ.get("AL_SPLIT", "1" if (plan.log2_block == 13 and not fused) or quad16 else "0") == "1"
         if want_split and plan.log2_block >= 11:

@@ -106,19 +106,41 @@ int al_plan_create(const al_event_spec *specs, int32_t n_events, int32_t n_capsu
     int32_t longest = 1;
     for (int i = 0; i < n_events; ++i) longest = std::max(longest, specs[i].n_samples);
     log2_block = al_choose_log2_block(ir_len, longest);
-    // B = 16384 (four 4096-point transforms per window, csrc/al_quad16.h) for big batches of static events with 17..24 partitions
-    // of 8192: the accumulate is back in the capsule loop's register tile (<= 12 partitions: 5.2 instead of 4.1 TB/s on cfg5), which
-    // pays for the slower transforms from about 100 000 (capsule, block) rows on (profiles/r04u_quad16_ir_sweep_*.txt: -4..-11 % per
-    // batch from there on, -2..+5 % at half that size, slower everywhere outside 17..24).  Moving events: not measured, so not switched.
+    // B = 16384 (four 4096-point transforms per window, csrc/al_quad16.h) in the two situations it was measured to pay:
     const int64_t p13 = ((int64_t)ir_len + 8191) / 8192;
-    if (log2_block == 13 && p13 >= 17 && p13 <= 24) {
+    bool any_moving = false;
+    for (int i = 0; i < n_events; ++i) any_moving = any_moving || specs[i].n_emitters > 1;
+    if (log2_block == 13 && !any_moving && p13 >= 17 && p13 <= 24) {
+      // (1) big batches of static events with 17..24 partitions of 8192: the accumulate is back in the capsule loop's register tile
+      // (<= 12 partitions: 5.2 instead of 4.1 TB/s on cfg5), which pays for the slower transforms from about 100 000 (capsule, block)
+      // rows on (profiles/r04u_quad16_ir_sweep_*.txt: -4..-11 % per batch from there on, -2..+5 % at half that size, slower
+      // everywhere outside 17..24)
       int64_t blocks = 0;
-      bool all_static = true;
-      for (int i = 0; i < n_events; ++i) {
-        blocks += ((int64_t)specs[i].n_samples + 8191) / 8192;
-        all_static = all_static && specs[i].n_emitters <= 1 && !specs[i].is_moving;
+      for (int i = 0; i < n_events; ++i) blocks += ((int64_t)specs[i].n_samples + 8191) / 8192;
+      if (blocks * n_capsules >= 100000) log2_block = 14;
+    } else if (log2_block == 13 && any_moving) {
+      // (2) moving events that fall off the sliding-window accumulate at B = 8192 (a cross-fade window of more than AL_SPARSE_MAX_NJ
+      // blocks, or more than AL_SPARSE_MAX_PARTITIONS partitions: the tile kernel sums over streams instead) but not at B = 16384:
+      // -5..-31 % per batch (profiles/r04z_quad16_moving_sweep*.txt).  Where both sizes are eligible the smaller block wins
+      // (shorter zero-padded windows: cfg3's shape with 2.3-4 s IRs is 7-14 % slower at 16384), so nothing changes there.
+      auto all_sliding = [&](int32_t lb, al_plan **made) -> bool {
+        if ((((int64_t)ir_len + ((int64_t)1 << lb) - 1) >> lb) > AL_SPARSE_MAX_PARTITIONS) return false;
+        if (al_plan_create(specs, n_events, n_capsules, ir_len, sample_rate, lb, hop, win, fft_size, made) != AL_OK) return false;
+        for (int i = 0; i < n_events; ++i)
+          if (specs[i].n_emitters > 1 && (*made)->events[i].reserved != 1) return false;
+        return true;
+      };
+      al_plan *p13_plan = nullptr, *p14_plan = nullptr;
+      const bool ok13 = all_sliding(13, &p13_plan);
+      const bool ok14 = !ok13 && all_sliding(14, &p14_plan);
+      al_plan *keep = ok14 ? p14_plan : p13_plan;
+      if (keep != p13_plan) al_plan_destroy(p13_plan);
+      if (keep != p14_plan) al_plan_destroy(p14_plan);
+      if (keep) {          // one of the two trial plans IS the result
+        *out = keep;
+        return AL_OK;
       }
-      if (all_static && blocks * n_capsules >= 100000) log2_block = 14;
+      // neither could be made (the error of the explicit call below is the caller's)
     }
   }
   if (log2_block < AL_MIN_LOG2_BLOCK || log2_block > AL_MAX_LOG2_BLOCK) return plan_fail(AL_E_UNSUPPORTED, "log2_block must be in [10, 14]");

@@ -204,11 +204,23 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
         raise ValueError("the HIP time-variant path needs win_size == 2*hop_size (sin^2 COLA) and fft_size >= 2*win_size-1")
     if log2_block is None:
         log2_block = choose_log2_block(ir_len, max([s.n_samples for s in specs], default=1))
-        # big batches of static events with 17..24 partitions of 8192: B = 16384 (al_plan_create, csrc/al_plan.cpp)
+        # B = 16384 in the two situations al_plan_create (csrc/al_plan.cpp) switches to it
         p13 = -(-ir_len // 8192)
-        if log2_block == 13 and 17 <= p13 <= 24 and all(s.n_emitters <= 1 and not s.is_moving for s in specs) \
-                and n_capsules * sum(-(-s.n_samples // 8192) for s in specs) >= 100000:
-            log2_block = 14
+        any_moving = any(s.n_emitters > 1 for s in specs)
+        if log2_block == 13 and not any_moving and 17 <= p13 <= 24:
+            # (1) big batches of static events with 17..24 partitions of 8192
+            if n_capsules * sum(-(-s.n_samples // 8192) for s in specs) >= 100000:
+                log2_block = 14
+        elif log2_block == 13 and any_moving:
+            # (2) moving events that are off the sliding-window accumulate at B = 8192 but on it at B = 16384
+            def all_sliding(lb):
+                if -(-ir_len // (1 << lb)) > SPARSE_MAX_PARTITIONS:
+                    return None
+                pl = plan_batch(specs, n_capsules, ir_len, sample_rate, log2_block=lb, hop=hop, win=win, fft_size=fft_size)
+                return pl if all(int(pl.events["reserved"][i]) == 1 for i, s in enumerate(specs) if s.n_emitters > 1) else None
+
+            if all_sliding(13) is None and all_sliding(14) is not None:
+                log2_block = 14
     if not MIN_LOG2_BLOCK <= log2_block <= MAX_LOG2_BLOCK:
         raise ValueError(f"log2_block must be in [{MIN_LOG2_BLOCK}, {MAX_LOG2_BLOCK}]")
     B = 1 << log2_block

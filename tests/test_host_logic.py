@@ -367,8 +367,37 @@ def test_planner_block_size_rule_for_long_irs():
     assert both(128, 64, 8192 * 16).log2_block == 13                                                # 16 partitions
     assert both(128, 64, 8192 * 24 + 1).log2_block == 13                                            # 25 partitions
     assert both(32, 32, 192000).log2_block == 13                                                    # small batch
-    assert both(128, 64, 192000, moving_at=5).log2_block == 13                                      # a moving event: not measured
+    assert both(128, 64, 192000, moving_at=5).log2_block == 13                                      # a moving event on the sliding window at 8192: rule (2) keeps it
     assert planning.plan_batch([planning.EventSpec(192000, 1, 5.0)] * 128, 64, 192000, 48000.0, log2_block=13).log2_block == 13   # the caller's choice stands
+
+
+def test_planner_block_size_rule_for_moving_events():
+    """al_plan_create, rule (2): a batch with moving events gets B = 16384 exactly when some moving event is off the sliding-window
+    accumulate at B = 8192 (a cross-fade window of more than AL_SPARSE_MAX_NJ blocks, or more than AL_SPARSE_MAX_PARTITIONS
+    partitions) and all of them are on it at 16384 (profiles/r04z_quad16_moving_sweep*.txt); the numpy planner agrees."""
+    from tests import plan_reference as ref
+
+    def both(n_irs, ir_len, n_samples=372000, with_static=False):
+        kw = [dict(n_samples=n_samples, n_emitters=n_irs, snr=5.0, emitter0=0, is_moving=True, duration=n_samples / 48000.0)]
+        if with_static:
+            kw.append(dict(n_samples=100000, n_emitters=1, snr=5.0, emitter0=n_irs))
+        a = planning.plan_batch([planning.EventSpec(**k) for k in kw], 4, ir_len, 48000.0)
+        b = ref.plan_batch([ref.EventSpec(**k) for k in kw], 4, ir_len, 48000.0)
+        assert a.log2_block == b.log2_block and a.events.tobytes() == b.events.tobytes() and a.streams.tobytes() == b.streams.tobytes()
+        return a
+
+    pl = both(32, 96000)                       # cfg3: windows of 2.84 blocks, 12 partitions: on the sliding window at 8192
+    assert pl.log2_block == 13 and int(pl.events["reserved"][0]) == 1
+    pl = both(32, 192000)                      # 24 partitions: still eligible
+    assert pl.log2_block == 13
+    pl = both(32, 200000)                      # 25 partitions of 8192: only 16384 keeps the event on the sliding window
+    assert pl.log2_block == 14 and pl.n_partitions == 13 and int(pl.events["reserved"][0]) == 1
+    pl = both(16, 96000)                       # 16 waypoints: windows of 5.7 blocks of 8192 reach 7-8 signal blocks, 4 at 16384
+    assert pl.log2_block == 14 and int(pl.events["reserved"][0]) == 1
+    assert both(16, 96000, with_static=True).log2_block == 14
+    pl = both(4, 96000)                        # windows of 23 blocks: off it at either size -> the default stays
+    assert pl.log2_block == 13 and int(pl.events["reserved"][0]) == 0
+    assert both(32, 8192 * 48 + 1).log2_block == 13        # 25 partitions of 16384: neither
 
 
 def test_every_accumulate_instantiation_is_named_by_a_gpu_test():

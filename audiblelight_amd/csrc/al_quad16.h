@@ -167,12 +167,27 @@ __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], c
 }
 
 // ------------------------------------------------------------------ 1q. IR partition spectra
-#ifndef AL_Q16_RUN
-#define AL_Q16_RUN 4   /* consecutive partitions of one IR row per workgroup: the next one is requested while this one is transformed */
-#endif
-static inline int quad16_runs(const al_batch *b) { return (b->n_partitions + AL_Q16_RUN - 1) / AL_Q16_RUN; }
+// A workgroup walks a RUN of consecutive partitions of one IR row (the next one requested while this one is transformed).  Runs of
+// unequal length in one launch cost more than their work (P = 5 as 4 + 1: 4.8 ms, as one run of 5: 3.7 ms, as five of 1: 3.8 ms on
+// a 16 384-row batch, profiles/r04z_forward_run_variants_moving.txt), so a row is cut into EQUAL runs of 2..6 partitions where its
+// partition count allows (cfg5: 12 as 6 + 6), the whole row otherwise -- shorter only if the batch has too few rows to fill the chip.
+// AL_FLAG_IR_RUN(n) is the caller's own choice of run length.
+static inline int quad16_run_len(const al_batch *b) {
+  const int P = b->n_partitions, forced = (b->flags >> 24) & 0x7f;
+  if (forced) return forced < P ? forced : P;
+  const int64_t rows = (int64_t)b->n_capsules * b->n_emitters;
+  int pick = 0;
+  for (int n_runs = 1; n_runs <= P; ++n_runs) {
+    if (P % n_runs || (rows * n_runs < 1024 && n_runs < P)) continue;   // equal runs only; enough workgroups to fill the chip
+    const int run = P / n_runs;
+    if (!pick) pick = run;                                               // the whole row, if nothing shorter divides it
+    if (run >= 2 && run <= 6) return run;                                // long enough to hide the hand-over, short enough to spread
+  }
+  return pick ? pick : 1;
+}
+static inline int quad16_runs(const al_batch *b, int run_len) { return (b->n_partitions + run_len - 1) / run_len; }
 
-__device__ __forceinline__ void ir_spectra_quad16_body(const al_batch &b, float2 *s, float *red, int run, int c, int nz) {
+__device__ __forceinline__ void ir_spectra_quad16_body(const al_batch &b, float2 *s, float *red, int run, int run_len, int c, int nz) {
   using G = Quad16::G;
   constexpr int Q = Quad16::Q, B = Quad16::B, T = Quad16::T;
   int tid = threadIdx.x;
@@ -182,7 +197,7 @@ __device__ __forceinline__ void ir_spectra_quad16_body(const al_batch &b, float2
   load_fft_twiddles<G, -1, 4>(tw, table, tid);
   const float2 wt = table[tid];
   const float *row = b.ir + (int64_t)c * b.ir_stride_c + (int64_t)n_ir * b.ir_stride_n;
-  const int p0 = run * AL_Q16_RUN, p1 = min(p0 + AL_Q16_RUN, b.n_partitions);
+  const int p0 = run * run_len, p1 = min(p0 + run_len, b.n_partitions);
   const int p_live = (b.emitter_parts && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) ? b.emitter_parts[n_ir] : b.n_partitions;   // al_batch.emitter_parts
   // h[k][i] = h[p B + n + k Q], n = tid + 256 i, zeros past the IR's end; `half` 0: i < 8, 1: the rest
   auto request = [&](int p, float (&h)[4][16], int half) {
@@ -331,7 +346,7 @@ __device__ __forceinline__ void signal_spectra_quad16_body(const al_batch &b, fl
 }
 
 // both forward transforms in one launch, as k_forward_spectra_split: workgroups [0, n_sig) are signal windows, the rest runs of IR partitions
-__global__ __launch_bounds__(256, AL_Q16_WAVES) void k_forward_spectra_quad16(al_batch b, int n_sig, int n_runs) {
+__global__ __launch_bounds__(256, AL_Q16_WAVES) void k_forward_spectra_quad16(al_batch b, int n_sig, int n_runs, int run_len) {
   __shared__ float2 s[Quad16::G::LDS_ELEMS];
   __shared__ float red[48];
   const int id = blockIdx.x;
@@ -339,14 +354,14 @@ __global__ __launch_bounds__(256, AL_Q16_WAVES) void k_forward_spectra_quad16(al
     signal_spectra_quad16_body(b, s, id % b.max_nj, id / b.max_nj);
   } else {
     const int q = id - n_sig, rc = n_runs * b.n_capsules;
-    ir_spectra_quad16_body(b, s, red, q % n_runs, (q / n_runs) % b.n_capsules, q / rc);
+    ir_spectra_quad16_body(b, s, red, q % n_runs, run_len, (q / n_runs) % b.n_capsules, q / rc);
   }
 }
 
-__global__ __launch_bounds__(256, AL_Q16_WAVES) void k_ir_spectra_quad16(al_batch b) {
+__global__ __launch_bounds__(256, AL_Q16_WAVES) void k_ir_spectra_quad16(al_batch b, int run_len) {
   __shared__ float2 s[Quad16::G::LDS_ELEMS];
   __shared__ float red[48];
-  ir_spectra_quad16_body(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
+  ir_spectra_quad16_body(b, s, red, blockIdx.x, run_len, blockIdx.y, blockIdx.z);
 }
 
 __global__ __launch_bounds__(256, AL_Q16_WAVES) void k_signal_spectra_quad16(al_batch b) {

@@ -259,7 +259,8 @@ static bool use_quad16(const al_batch *b) { return use_split(b) && (b->flags & A
 
 hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream) {
   if (use_quad16(b)) {
-    hipLaunchKernelGGL(k_ir_spectra_quad16, dim3(quad16_runs(b), b->n_capsules, b->n_emitters), dim3(Quad16::T), 0, stream, *b);
+    const int run_len = quad16_run_len(b);
+    hipLaunchKernelGGL(k_ir_spectra_quad16, dim3(quad16_runs(b, run_len), b->n_capsules, b->n_emitters), dim3(Quad16::T), 0, stream, *b, run_len);
     return hipGetLastError();
   }
   if (use_split(b)) {
@@ -280,9 +281,10 @@ hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream) {
     const int64_t n_sig = (int64_t)b->max_nj * b->n_streams;
     const int64_t n_ir = (int64_t)b->n_partitions * b->n_capsules * b->n_emitters;
     if (use_quad16(b)) {   // a workgroup per signal window and per run of IR partitions
-      const int64_t n_run = (int64_t)quad16_runs(b) * b->n_capsules * b->n_emitters;
+      const int run_len = quad16_run_len(b), n_runs = quad16_runs(b, run_len);
+      const int64_t n_run = (int64_t)n_runs * b->n_capsules * b->n_emitters;
       if (n_sig + n_run <= 0x7fffffff) {
-        hipLaunchKernelGGL(k_forward_spectra_quad16, dim3((unsigned)(n_sig + n_run)), dim3(Quad16::T), 0, stream, *b, (int)n_sig, quad16_runs(b));
+        hipLaunchKernelGGL(k_forward_spectra_quad16, dim3((unsigned)(n_sig + n_run)), dim3(Quad16::T), 0, stream, *b, (int)n_sig, n_runs, run_len);
         return hipGetLastError();
       }
     } else if (n_sig + n_ir <= 0x7fffffff) {

@@ -68,7 +68,8 @@ extern "C" {
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
-#define AL_FLAG_IR_RUN(n) (((n) & 0x7f) << 24)    /* al_ir_spectra: n consecutive partitions per workgroup (0 = 1) */
+#define AL_FLAG_IR_RUN(n) (((n) & 0x7f) << 24)    /* al_ir_spectra: n consecutive partitions per workgroup (0 = 1; the B = 16384 quad-tile
+                                                     kernels: 0 = chosen per batch, equal runs, csrc/al_quad16.h) */
 
 #define AL_SPARSE_MAX_NJ 6          /* longest stream (in blocks) the sliding-window accumulate accepts */
 #define AL_SPARSE_MAX_PARTITIONS 24 /* most IR partitions it accepts */

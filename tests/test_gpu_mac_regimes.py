@@ -228,7 +228,13 @@ def test_quad16_transforms_all_rows(gpu, monkeypatch):
     partition and edge windows, a moving event (the rolled general signal path, sliding-window accumulate), every row against
     the oracle; then the separate IR / signal launches (al_ir_spectra + al_signal_spectra) against the merged one, bit for bit."""
     monkeypatch.delenv("AL_QUAD16", raising=False)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(4 << 24))       # AL_FLAG_IR_RUN(4): three runs of four partitions (a batch this small gets runs of one)
     res = mr.run_static_case(gpu, 14, 3121201, 192000 / 16384, 192000 / 16384, C=3, E=2, expect_split=True, expect_quad=True)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(12 << 24))      # one run of twelve, as the full-size cfg5 batch runs
+    mr.run_static_case(gpu, 14, 3121201, 192000 / 16384, 192000 / 16384, C=2, E=1, expect_split=True, expect_quad=True)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(5 << 24))       # unequal runs: 5 + 2
+    mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)
+    monkeypatch.delenv("AL_EXTRA_FLAGS")
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 12
     mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=True, expect_quad=True)
     mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)

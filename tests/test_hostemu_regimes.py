@@ -86,7 +86,11 @@ def test_emu_quad16_transforms(emu, monkeypatch):
     envelopes (moving event), the inverse that assembles a block from the four tiles; every row against the oracle.  And with
     AL_QUAD16=0 the one-transform kernels of round 1 still serve B = 16384."""
     monkeypatch.delenv("AL_QUAD16", raising=False)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(3 << 24))       # AL_FLAG_IR_RUN(3): one run of three partitions per IR row (a batch this small gets runs of one)
     mr.run_static_case(emu, 14, 3120301, 3.5, 2.5, C=2, E=2, expect_split=True, expect_quad=True)
+    monkeypatch.setenv("AL_EXTRA_FLAGS", str(2 << 24))       # unequal runs: 2 + 1
+    mr.run_static_case(emu, 14, 3120301, 3.5, 2.5, C=1, E=1, expect_split=True, expect_quad=True)
+    monkeypatch.delenv("AL_EXTRA_FLAGS")
     mr.run_moving_case(emu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
     mr.run_separate_forward_launches(emu, 14)
     monkeypatch.setenv("AL_QUAD16", "0")

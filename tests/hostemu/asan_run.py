@@ -100,9 +100,12 @@ irs = (rng.standard_normal((2, 1 + 3, Lir)) * np.exp(-np.arange(Lir) / (Lir / 5.
 specs = [planning.EventSpec(n_samples=La, n_emitters=1, snr=10.0, emitter0=0),
          planning.EventSpec(n_samples=len(clips[1]), n_emitters=3, snr=12.0, emitter0=1, is_moving=True, duration=len(clips[1]) / 48000)]
 pl = planning.plan_batch(specs, 2, Lir, 48000, log2_block=14)
-batch = r.prepare(pl, clips, irs)
-assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA
-res = batch.run()
-res.check_finite()
-print("asan run ok: quad-tile transforms at B = 16384", float(np.abs(res.spatial_audio(0)).sum()))
+for run_len in (0, 3):          # a batch this small gets runs of one partition; AL_FLAG_IR_RUN(3): 3 + 2, the hand-over between partitions
+    os.environ["AL_EXTRA_FLAGS"] = str(run_len << 24)
+    batch = r.prepare(pl, clips, irs)
+    assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA
+    res = batch.run()
+    res.check_finite()
+    print("asan run ok: quad-tile transforms at B = 16384, runs of", run_len or 1, float(np.abs(res.spatial_audio(0)).sum()))
+del os.environ["AL_EXTRA_FLAGS"]
 print("asan run ok: round-4 kernels")

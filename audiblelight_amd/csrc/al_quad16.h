@@ -167,10 +167,13 @@ __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], c
 }
 
 // ------------------------------------------------------------------ 1q. IR partition spectra
-// A workgroup walks a RUN of consecutive partitions of one IR row (the next one requested while this one is transformed).  Runs of
-// unequal length in one launch cost more than their work (P = 5 as 4 + 1: 4.8 ms, as one run of 5: 3.7 ms, as five of 1: 3.8 ms on
-// a 16 384-row batch, profiles/r04z_forward_run_variants_moving.txt), so a row is cut into EQUAL runs of 2..6 partitions where its
-// partition count allows (cfg5: 12 as 6 + 6), the whole row otherwise -- shorter only if the batch has too few rows to fill the chip.
+// A workgroup walks a RUN of consecutive partitions of one IR row (the next one requested while this one is transformed).  The run
+// index is the fastest-varying part of the workgroup id and ids are dealt round-robin over the 8 XCDs, so runs of unequal length put
+// the long ones on some XCDs and the short ones on the others: 5 partitions as 4 + 1 send every run of four to four of the eight
+// XCDs (4.8 ms on a 16 384-row batch; as one run of 5: 3.7 ms, as five of 1: 3.8 ms, and 3.7 ms again as 4 + 1 with the run index
+// SLOWEST: profiles/r04z_forward_run_variants_moving.txt, r04z_unequal_runs_xcd_probe.txt).  So a row is cut into EQUAL runs of 2..6
+// partitions where its partition count allows (cfg5: 12 as 6 + 6), the whole row otherwise -- shorter only if the batch has too few
+// rows to fill the chip.
 // AL_FLAG_IR_RUN(n) is the caller's own choice of run length.
 static inline int quad16_run_len(const al_batch *b) {
   const int P = b->n_partitions, forced = (b->flags >> 24) & 0x7f;

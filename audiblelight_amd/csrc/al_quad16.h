@@ -97,9 +97,10 @@ __device__ __forceinline__ void quad16_fft(float2 (&v)[16], float2 *s, FftTwiddl
 // ------------------------------------------------------------------ forward: the four tiles of one window
 // sk[k][i] = s[n + k Q], dk[k][i] = d[n + k Q] at n = tid + 256 i (an IR partition: the same array twice).  The samples are read
 // ONCE (a workgroup that comes back for them a transform later finds most of them gone from the L2: +20 % on the kernel,
-// profiles/r04s_quad16_ab_v1_reread.txt), so the inputs of all four transforms are made here and held: 128 registers, which is why these
-// kernels are compiled for two waves per SIMD.  `prefetch(0)` is called once tiles 2 and 3 are stored, `prefetch(1)` after tile 1:
-// the caller requests one half of its next window at each, into the registers that have become free.
+// profiles/r04s_quad16_ab_v1_reread.txt) and held across the transforms -- 64 values for an IR partition, 96 for a signal window --
+// which is why these kernels are compiled for two waves per SIMD.  `prefetch(0)` is called once tiles 2 and 3 are stored and the
+// samples are no longer needed, `prefetch(1)` after tile 1: the caller requests one half of its next window at each, into the
+// registers that have become free.
 template <bool SAME, class Prefetch>
 __device__ __forceinline__ void quad16_forward_tiles(const float (&sk)[4][16], const float (&dk)[4][16], float2 *__restrict__ out, float2 *s,
                                                      FftTwiddles<Quad16::G> &tw, float2 wt, int tid, Prefetch &&prefetch) {

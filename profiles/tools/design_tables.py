@@ -1,0 +1,59 @@
+"""Regenerate the two result tables of DESIGN.md (section 5 kernel table, section 7 config table) from the round's profile files:
+profiles/r04_cfgN_kernel_stats.csv, profiles/pmc_traffic.json, profiles/r04_bench_cfgN.json.   python3 profiles/tools/design_tables.py"""
+import csv
+import json
+import os
+import re
+
+R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+p = os.path.join(R, "DESIGN.md")
+s = open(p).read()
+t = json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))
+CFGS = ("cfg2", "cfg3", "cfg4", "cfg5")
+LB = {"cfg2": 13, "cfg3": 13, "cfg4": 13, "cfg5": 14}
+
+
+def kms(c):
+    out = {}
+    for r in csv.DictReader(open(os.path.join(R, "profiles", f"r04_{c}_kernel_stats.csv"))):
+        for key, stage in (("forward_spectra", "f"), ("spectral_mac", "m"), ("block_synthesis", "s"), ("k_mixdown", "x"), ("emitter_gains", "g"), ("event_levels", "l")):
+            if key in r["Name"]:
+                out[stage] = out.get(stage, 0) + float(r["AverageNs"]) / 1e6
+    return out
+
+
+def cell(c, stage, key, bold=False):
+    ms, gb = kms(c)[stage], t[f"{c}/log2_block={LB[c]}"][key] / 1e9
+    txt = f"{ms:.3f}, {gb:.2f}, {gb / ms:.1f}" if ms < 1 else f"{ms:.2f}, {gb:.1f}, {gb / ms:.1f}"
+    return f"**{txt}**" if bold else txt
+
+
+d = {c: json.loads(open(os.path.join(R, "profiles", f"r04_bench_{c}.json")).read().strip().splitlines()[-1]) for c in CFGS}
+d2b = json.loads(open(os.path.join(R, "profiles", "r04_bench_cfg2_steps20.json")).read().strip().splitlines()[-1])
+tot = {c: sum(t[f"{c}/log2_block={LB[c]}"].values()) / 1e9 for c in CFGS}
+small = {c: kms(c)["g"] + kms(c)["l"] for c in CFGS}
+k = {c: kms(c) for c in CFGS}
+fmt = lambda v: format(int(round(v)), ",").replace(",", " ")
+fr = lambda c: f"{d[c]['roofline']['frac']:.3f} / {d[c]['roofline']['path_frac']:.3f}"
+
+a = s.index("| forward transforms (IR partitions + signal windows): `k_forward_spectra_split<13>`")
+b = s.index("Every kernel moves the bytes its row says")
+s = s[:a] + f"""| forward transforms (IR partitions + signal windows): `k_forward_spectra_split<13>` (two 4096-point FFTs per window); cfg5 `k_forward_spectra_quad16` (four per window of twice the size) | {cell('cfg2', 'f', 'al_forward_spectra')} | {cell('cfg3', 'f', 'al_forward_spectra')} | {cell('cfg4', 'f', 'al_forward_spectra')} | {cell('cfg5', 'f', 'al_forward_spectra')} |
+| accumulate: `k_spectral_mac_static<12,P,NKTW>` (cfg2 P = 12, two k-tiles; cfg4 P = 6; cfg5 P = 12, one k-tile), `k_spectral_mac_moving<6,12,1>` (cfg3) | {cell('cfg2', 'm', 'al_spectral_mac', True)} | {cell('cfg3', 'm', 'al_spectral_mac')} | {cell('cfg4', 'm', 'al_spectral_mac')} | {cell('cfg5', 'm', 'al_spectral_mac', True)} |
+| inverse transforms + overlap-save: `k_block_synthesis_split<13>`; cfg5 `k_block_synthesis_quad16` | {cell('cfg2', 's', 'al_block_synthesis')} | {cell('cfg3', 's', 'al_block_synthesis')} | {cell('cfg4', 's', 'al_block_synthesis', True)} | {cell('cfg5', 's', 'al_block_synthesis')} |
+| `k_mixdown` | {cell('cfg2', 'x', 'al_mixdown')} | {cell('cfg3', 'x', 'al_mixdown')} | {cell('cfg4', 'x', 'al_mixdown')} | {cell('cfg5', 'x', 'al_mixdown')} |
+| `k_emitter_gains`, `k_event_levels` | {small['cfg2']:.3f} | {small['cfg3']:.3f} | {small['cfg4']:.3f} | {small['cfg5']:.3f} |
+| scene (bench, median of 3 x K steps; box-to-box spread of the pool about 3 %; kernel rows above are from the profiler runs of the same box) | **{d['cfg2']['ms_per_step']:.2f} ms** (2.65-2.74 over the boxes), {tot['cfg2']:.2f} GB | **{d['cfg3']['ms_per_step']:.2f} ms** (6.6-6.9), {tot['cfg3']:.2f} GB | **{d['cfg4']['ms_per_step']:.2f} ms**, {tot['cfg4']:.2f} GB | **{d['cfg5']['ms_per_step']:.2f} ms** (13.7-14.2; round 3 and B = 8192: 14.9-15.1), {tot['cfg5']:.1f} GB |
+| algorithmic bytes (SURVEY 8d), `roofline.frac` / `path_frac` | 1.204 GB: {fr('cfg2')} | 6.68 GB: {fr('cfg3')} | 0.406 GB: {fr('cfg4')} | 7.13 GB: {fr('cfg5')} |
+
+""" + s[b:]
+a = re.search(r"\| cfg2 \(headline\) \| \d", s).start()
+b = s.index("cfg2, cfg3 and cfg4 are unchanged from round 3 within box-to-box spread")
+s = s[:a] + f"""| cfg2 (headline) | {d['cfg2']['ms_per_step']:.2f} ({d2b['ms_per_step']:.2f} with the driver's `--steps 20`; 2.65-2.74 over the boxes of the pool) | **{fmt(round(d['cfg2']['value'], -2))}** (21 900-22 650) | `al_spectral_mac` {k['cfg2']['m']:.3f} ms | {fr('cfg2')} | {tot['cfg2']:.2f} GB vs 1.204 GB = 11.9x | {d['cfg2']['cpu_baseline']['value']:.1f} / **14.3 measured in full** ({d['cfg2']['cpu_baseline_all_cores']['value']:.1f} from the default bounded sample of this run, 12-15 across runs) |
+| cfg3 (16 moving events x 32 IRs) | {d['cfg3']['ms_per_step']:.2f} (6.6-6.9 over the boxes) | {fmt(d['cfg3']['value'])} | `al_forward_spectra` {k['cfg3']['f']:.2f} ms | {fr('cfg3')} | {tot['cfg3']:.2f} GB vs 6.68 GB = 5.4x | 0.64 (1 of 16 events, 8 of 32 IRs, extrapolated) |
+| cfg4 (30 s scene, 32 events, 1 s RIR) | {d['cfg4']['ms_per_step']:.2f} | {fmt(d['cfg4']['value'])} | `al_block_synthesis` {k['cfg4']['s']:.3f} ms | {fr('cfg4')} | {tot['cfg4']:.2f} GB vs 0.406 GB = 15.1x | 5.0 (whole scene) |
+| cfg5 (64 capsules, 128 events, 4 s RIR, ambience, folded FX; B = 16384) | **{d['cfg5']['ms_per_step']:.2f}** (13.7-14.2 over the boxes; round 3: 14.9-15.1) | **{fmt(d['cfg5']['value'])}** | `al_spectral_mac` {d['cfg5']['roofline']['kernel_ms']['al_spectral_mac']:.2f} ms in the bench run ({k['cfg5']['m']:.2f} under the profiler; 26.0 GB, 4.9-5.2 TB/s) | {fr('cfg5')} | {tot['cfg5']:.1f} GB vs 7.13 GB = 10.2x | 0.73 (4 of 128 events, extrapolated) |
+
+""" + s[b:]
+open(p, "w").write(s)
+print("DESIGN.md tables regenerated")

@@ -419,7 +419,11 @@ int32_t al_stft_frame_count(int64_t n_samples, int32_t hop);                    
 int32_t al_interpolation_rows(int32_t n_irs, double duration, double sample_rate, int32_t hop);
 /* generate_interpolation_matrix (synthesize.py:148-181) for ir_times = linspace(0, duration, n_irs): rows x n_irs float64 */
 int al_interpolation_matrix(int32_t n_irs, double duration, double sample_rate, int32_t hop, int32_t rows, double *weights);
-/* log2_block <= 0: chosen from the lengths.  Errors carry the reference's messages ("Moving Event has only one emitter!", ...). */
+/* log2_block <= 0: chosen from the lengths (al_choose_log2_block: 8192 from 4096 samples of IR and clip up), and 16384 in the two
+ * situations it was measured to pay (csrc/al_plan.cpp): batches of at least 100 000 (capsule, block) rows of static events with
+ * 17..24 partitions of 8192, and batches whose moving events are off the sliding-window accumulate at 8192 but on it at 16384.  Read
+ * the choice back from al_plan_info.log2_block and set the layout flags for it (AL_FLAG_SPLIT_SPECTRA at 13, + AL_FLAG_QUAD_SPECTRA
+ * at 14).  Errors carry the reference's messages ("Moving Event has only one emitter!", ...). */
 int al_plan_create(const al_event_spec *specs, int32_t n_events, int32_t n_capsules, int32_t ir_len, double sample_rate,
                    int32_t log2_block, int32_t hop, int32_t win, int32_t fft_size, al_plan **out);
 void al_plan_destroy(al_plan *plan);

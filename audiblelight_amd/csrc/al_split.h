@@ -214,8 +214,12 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
   if (id < n_sig) {
     signal_spectra_split_body<LOG2M, QUAD>(b, s, id % b.max_nj, id / b.max_nj);
   } else {
-    const int q = id - n_sig, pc = b.n_partitions * b.n_capsules;
-    ir_spectra_split_body<LOG2M, QUAD>(b, s, red, q % b.n_partitions, (q / b.n_partitions) % b.n_capsules, q / pc);
+    // Workgroup ids are dealt round-robin over the 8 XCDs; with the partition index as the plain remainder of the id an XCD would
+    // only ever see partitions of one residue class (12 partitions per row: p mod 4 fixed per XCD), and the trimmed late
+    // partitions of moving events (al_batch.emitter_parts) would be some XCDs' work only.  Rotating the index by the row gives every
+    // XCD every partition: -2 % on cfg2's launch, -0.4 % on cfg3's (profiles/r04z_forward_id_mapping_ab.txt).
+    const int q = id - n_sig, pc = b.n_partitions * b.n_capsules, row = q / b.n_partitions;
+    ir_spectra_split_body<LOG2M, QUAD>(b, s, red, (q + row) % b.n_partitions, row % b.n_capsules, q / pc);
   }
 }
 

@@ -239,13 +239,20 @@ __global__ __launch_bounds__(256) void k_spectral_mac(al_batch b) {
 // NKTW: k-tiles per workgroup (256 threads each).  Two k-tiles of one (event, bin tile) read the SAME partition spectra;
 // in one workgroup, kept in step by a barrier per capsule, the second read of every line is an L1 hit on the same CU
 // instead of a second trip to L2 / HBM by another workgroup that may have drifted away.
+// The capsule-loop kernels' bin tile: blockIdx.x rotated by blockIdx.z.  Workgroup ids are dealt round-robin over the 8 XCDs and the
+// grids are 16 (or 32) bin tiles wide, so with the plain index an XCD would only ever touch two of the sixteen 4 KB columns of every
+// spectrum block; rotated, every XCD sees every column: -3 % on the accumulate of cfg2, cfg4 and cfg5
+// (profiles/r04z_rotated_ids_mac_synth_ab.txt).  (The tile kernel k_spectral_mac keeps the plain index: it WANTS the k-tiles of one
+// bin tile on one XCD, for the L2 hits on H; the sliding-window kernel is 3.5 % slower rotated, r04z_rotated_ids_moving_ab.txt.)
+__device__ __forceinline__ int rotated_bin_tile() { return (int)((blockIdx.x + blockIdx.z) % gridDim.x); }
+
 template <int KT, int PT, bool BIN0, int NKTW>
-__device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
+__device__ __forceinline__ void spectral_mac_static_body(const al_batch &b, int bx) {
   using V = BinVec<2>;
   constexpr int NJ = KT + PT - 1;
   const int M = 1 << b.log2_block;
   const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8;
-  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int f = (bx * 256 + lane256) * 2;
   const int n_cs = gridDim.z / b.n_events;                      // capsule ranges per event (small batches)
   const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
   const al_event ev = b.events[b.event0 + e];
@@ -313,8 +320,9 @@ __device__ __forceinline__ void spectral_mac_static_body(const al_batch &b) {
 
 template <int KT, int PT, int NKTW>
 __global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch b) {
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_body<KT, PT, true, NKTW>(b);
-  else spectral_mac_static_body<KT, PT, false, NKTW>(b);
+  const int bx = rotated_bin_tile();
+  if (bx == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_body<KT, PT, true, NKTW>(b, bx);
+  else spectral_mac_static_body<KT, PT, false, NKTW>(b, bx);
 }
 
 // Variant of the two-k-tile workgroup for clips of more than 24 blocks (several workgroups per (event, bin tile), all reading
@@ -322,14 +330,14 @@ __global__ __launch_bounds__(256 * NKTW, 2) void k_spectral_mac_static(al_batch 
 // while capsule c is multiplied, so H enters the CU once instead of twice (the second k-tile's L1 hit) and no partition
 // spectrum waits in registers.  Equal to the register version at K <= 24, 8-10 % faster beyond (profiles/r02_mac.txt 10).
 template <int KT, int PT, int UNITS, bool BIN0>
-__device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, float4 *hbuf) {
+__device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, float4 *hbuf, int bx) {
   // UNITS = 2: 13..16 partitions as two units of PT = ceil(P / 2) per capsule (the pipeline step is a unit; for odd P the
   // last unit's missing partition is stored as zeros in its LDS stage, so nothing in the products is masked)
   using V = BinVec<2>;
   constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PER = (STAGE + 511) / 512;
   const int M = 1 << b.log2_block;
   const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8;
-  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int f = (bx * 256 + lane256) * 2;
   const int n_cs = gridDim.z / b.n_events;
   const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
   const al_event ev = b.events[b.event0 + e];
@@ -342,7 +350,7 @@ __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, 
   const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
   const bool packed = (f == 0);
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
-  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + blockIdx.x * 512;
+  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + bx * 512;
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + k0) * M + f;
   const float g = b.emitter_gain[st.emitter];
   V xw[NJ];
@@ -427,8 +435,9 @@ __device__ __forceinline__ void spectral_mac_static_lds_body(const al_batch &b, 
 template <int KT, int PT, int UNITS = 1>
 __global__ __launch_bounds__(512, 2) void k_spectral_mac_static_lds(al_batch b) {
   __shared__ float4 hbuf[3 * PT * 256];
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, UNITS, true>(b, hbuf);
-  else spectral_mac_static_lds_body<KT, PT, UNITS, false>(b, hbuf);
+  const int bx = rotated_bin_tile();
+  if (bx == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_lds_body<KT, PT, UNITS, true>(b, hbuf, bx);
+  else spectral_mac_static_lds_body<KT, PT, UNITS, false>(b, hbuf, bx);
 }
 
 // ------------------------------------------------------------------ 4a'. capsule loop fed by LDS-DMA
@@ -465,13 +474,13 @@ __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" :
 // ds_read_b128 per capsule and frees 24 VGPRs, which is what the 32-block window of 19..21 partitions (NL = 2) needs to stay
 // out of scratch memory (a spill reload would also drain the LDS-DMA in flight: hipcc waits vmcnt(0) for it).
 template <int KT, int PT, int UNITS, bool BIN0, bool ZERO_ROWS = (UNITS > 1), int NL = 0, int NKTW = 2>
-__device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b, float4 *hbuf, float4 *xbuf = nullptr) {
+__device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b, float4 *hbuf, float4 *xbuf, int bx) {
   using V = BinVec<2>;
   constexpr int NWAVES = 4 * NKTW;      // NKTW k-tiles of 256 threads per workgroup
   constexpr int PALL = UNITS * PT, NJ = KT + PALL - 1, STAGE = PT * 256, PIECES = PT * 4, PER_WAVE = (PIECES + NWAVES - 1) / NWAVES;
   const int M = 1 << b.log2_block;
   const int lane256 = threadIdx.x & 255, sub = threadIdx.x >> 8, lane = threadIdx.x & 63;
-  const int f = (blockIdx.x * 256 + lane256) * 2;
+  const int f = (bx * 256 + lane256) * 2;
   const int n_cs = gridDim.z / b.n_events;
   const int e = blockIdx.z / n_cs, cs = blockIdx.z % n_cs;
   const al_event ev = b.events[b.event0 + e];
@@ -485,7 +494,7 @@ __device__ __forceinline__ void spectral_mac_static_glds_body(const al_batch &b,
   const int jlo = st.j_lo, jhi = st.j_lo + st.n_j;
   const bool packed = (f == 0);
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec) + (int64_t)(st.xspec_base - b.xspec_block0 - jlo) * M + f;
-  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + blockIdx.x * 512;
+  const float2 *__restrict__ Htile = reinterpret_cast<const float2 *>(b.hspec) + ((int64_t)(st.emitter - b.emitter0) * C * P) * M + bx * 512;
   const float2 *__restrict__ Hzero = reinterpret_cast<const float2 *>(b.hspec) + (int64_t)max(b.hspec_zero_block, 0) * M;   // rows past P (odd P in units)
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec) + ((int64_t)(ev.yspec_base - b.yspec_block0) + k0) * M + f;
   const float g = b.emitter_gain[st.emitter];
@@ -605,8 +614,9 @@ template <int KT, int PT, int UNITS = 1, bool ZERO_ROWS = (UNITS > 1), int NL = 
 __global__ __launch_bounds__(256 * NKTW, NKTW) void k_spectral_mac_static_glds(al_batch b) {
   __shared__ float4 hbuf[3 * PT * 256];
   __shared__ float4 xbuf[NL > 0 ? 2 * NL * 256 * NKTW : 1];
-  if (blockIdx.x == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_glds_body<KT, PT, UNITS, true, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf);
-  else spectral_mac_static_glds_body<KT, PT, UNITS, false, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf);
+  const int bx = rotated_bin_tile();
+  if (bx == 0 && (threadIdx.x & 255) < 64) spectral_mac_static_glds_body<KT, PT, UNITS, true, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf, bx);
+  else spectral_mac_static_glds_body<KT, PT, UNITS, false, ZERO_ROWS, NL, NKTW>(b, hbuf, xbuf, bx);
 }
 
 // ------------------------------------------------------------------ 4b. accumulate for moving events

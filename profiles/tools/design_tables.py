@@ -43,13 +43,13 @@ s = s[:a] + f"""| forward transforms (IR partitions + signal windows): `k_forwar
 | inverse transforms + overlap-save: `k_block_synthesis_split<13>`; cfg5 `k_block_synthesis_quad16` | {cell('cfg2', 's', 'al_block_synthesis')} | {cell('cfg3', 's', 'al_block_synthesis')} | {cell('cfg4', 's', 'al_block_synthesis', True)} | {cell('cfg5', 's', 'al_block_synthesis')} |
 | `k_mixdown` | {cell('cfg2', 'x', 'al_mixdown')} | {cell('cfg3', 'x', 'al_mixdown')} | {cell('cfg4', 'x', 'al_mixdown')} | {cell('cfg5', 'x', 'al_mixdown')} |
 | `k_emitter_gains`, `k_event_levels` | {small['cfg2']:.3f} | {small['cfg3']:.3f} | {small['cfg4']:.3f} | {small['cfg5']:.3f} |
-| scene (bench, median of 3 x K steps; box-to-box spread of the pool about 3 %; kernel rows above are from the profiler runs of the same box) | **{d['cfg2']['ms_per_step']:.2f} ms** (2.65-2.74 over the boxes), {tot['cfg2']:.2f} GB | **{d['cfg3']['ms_per_step']:.2f} ms** (6.6-6.9), {tot['cfg3']:.2f} GB | **{d['cfg4']['ms_per_step']:.2f} ms**, {tot['cfg4']:.2f} GB | **{d['cfg5']['ms_per_step']:.2f} ms** (13.7-14.2; round 3 and B = 8192: 14.9-15.1), {tot['cfg5']:.1f} GB |
+| scene (bench, median of 3 x K steps; box-to-box spread of the pool about 3 %; kernel rows above are from the profiler runs of the same box) | **{d['cfg2']['ms_per_step']:.2f} ms** (2.63-2.74 over the boxes), {tot['cfg2']:.2f} GB | **{d['cfg3']['ms_per_step']:.2f} ms** (6.6-6.9), {tot['cfg3']:.2f} GB | **{d['cfg4']['ms_per_step']:.2f} ms**, {tot['cfg4']:.2f} GB | **{d['cfg5']['ms_per_step']:.2f} ms** (13.7-14.2; round 3 and B = 8192: 14.9-15.1), {tot['cfg5']:.1f} GB |
 | algorithmic bytes (SURVEY 8d), `roofline.frac` / `path_frac` | 1.204 GB: {fr('cfg2')} | 6.68 GB: {fr('cfg3')} | 0.406 GB: {fr('cfg4')} | 7.13 GB: {fr('cfg5')} |
 
 """ + s[b:]
 a = re.search(r"\| cfg2 \(headline\) \| \d", s).start()
 b = s.index("cfg2, cfg3 and cfg4 are unchanged from round 3 within box-to-box spread")
-s = s[:a] + f"""| cfg2 (headline) | {d['cfg2']['ms_per_step']:.2f} ({d2b['ms_per_step']:.2f} with the driver's `--steps 20`; 2.65-2.74 over the boxes of the pool) | **{fmt(round(d['cfg2']['value'], -2))}** (21 900-22 650) | `al_spectral_mac` {k['cfg2']['m']:.3f} ms | {fr('cfg2')} | {tot['cfg2']:.2f} GB vs 1.204 GB = 11.9x | {d['cfg2']['cpu_baseline']['value']:.1f} / **14.3 measured in full** ({d['cfg2']['cpu_baseline_all_cores']['value']:.1f} from the default bounded sample of this run, 12-15 across runs) |
+s = s[:a] + f"""| cfg2 (headline) | {d['cfg2']['ms_per_step']:.2f} ({d2b['ms_per_step']:.2f} with the driver's `--steps 20`; 2.63-2.74 over the boxes of the pool) | **{fmt(round(d['cfg2']['value'], -2))}** (21 900-22 800) | `al_spectral_mac` {k['cfg2']['m']:.3f} ms | {fr('cfg2')} | {tot['cfg2']:.2f} GB vs 1.204 GB = 11.9x | {d['cfg2']['cpu_baseline']['value']:.1f} / **14.3 measured in full** ({d['cfg2']['cpu_baseline_all_cores']['value']:.1f} from the default bounded sample of this run, 12-15 across runs) |
 | cfg3 (16 moving events x 32 IRs) | {d['cfg3']['ms_per_step']:.2f} (6.6-6.9 over the boxes) | {fmt(d['cfg3']['value'])} | `al_forward_spectra` {k['cfg3']['f']:.2f} ms | {fr('cfg3')} | {tot['cfg3']:.2f} GB vs 6.68 GB = 5.4x | 0.64 (1 of 16 events, 8 of 32 IRs, extrapolated) |
 | cfg4 (30 s scene, 32 events, 1 s RIR) | {d['cfg4']['ms_per_step']:.2f} | {fmt(d['cfg4']['value'])} | `al_block_synthesis` {k['cfg4']['s']:.3f} ms | {fr('cfg4')} | {tot['cfg4']:.2f} GB vs 0.406 GB = 15.1x | 5.0 (whole scene) |
 | cfg5 (64 capsules, 128 events, 4 s RIR, ambience, folded FX; B = 16384) | **{d['cfg5']['ms_per_step']:.2f}** (13.7-14.2 over the boxes; round 3: 14.9-15.1) | **{fmt(d['cfg5']['value'])}** | `al_spectral_mac` {d['cfg5']['roofline']['kernel_ms']['al_spectral_mac']:.2f} ms in the bench run ({k['cfg5']['m']:.2f} under the profiler; 26.0 GB, 4.9-5.2 TB/s) | {fr('cfg5')} | {tot['cfg5']:.1f} GB vs 7.13 GB = 10.2x | 0.73 (4 of 128 events, extrapolated) |

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(_HERE, "csrc", "libaudiblelight_hip.so")
 
 AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
-ABI_VERSION = 5   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
+ABI_VERSION = 6   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
 FLAG_FUSED_STATIC = 2
@@ -138,6 +138,7 @@ SYMBOLS = {
     "al_workspace_bytes": (ct.c_int64, [_P]),
     "al_plan_chunk": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.POINTER(AlChunk)]),
     "al_plan_emitter_parts": (ct.c_int, [_P, ct.c_int32, _P]),
+    "al_plan_batch_flags": (ct.c_int, [_P, ct.POINTER(AlChunk), ct.POINTER(ct.c_int32)]),
     "al_plan_mixdown": (ct.c_int, [_P, _P, _P, _P, _P, _P, ct.c_int32, ct.c_double, ct.c_double, ct.c_int32, ct.c_int32,
                                    ct.POINTER(ct.c_void_p)]),
     "al_mix_plan_destroy": (None, [_P]),

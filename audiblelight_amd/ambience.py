@@ -91,10 +91,10 @@ def _flat_sigma(samples: int) -> float:
 
 
 def default_rng_mode() -> str:
-    mode = os.environ.get("AL_AMBIENCE_RNG", "host")
-    if mode not in ("host", "device"):
-        raise ValueError(f"AL_AMBIENCE_RNG must be 'host' or 'device', got {mode!r}")
-    return mode
+    """AL_AMBIENCE_RNG ("host" / "device"), parsed once with the other switches (switches.py)."""
+    from . import switches
+
+    return switches.current().ambience_rng
 
 
 def _clone(buf):

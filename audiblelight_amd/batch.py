@@ -23,7 +23,7 @@ from typing import Callable, Iterable, List, Optional, Sequence
 
 import numpy as np
 
-from . import _hip, engine
+from . import _hip, engine, switches
 from . import plan as planning
 
 
@@ -92,11 +92,12 @@ class BatchDriver:
         # AL_D2H=kernel: the encode / copy kernels store straight into page-locked host memory instead of a DMA on the
         # download stream; slower once uploads run from their own thread (the stores slow the concurrent H2D: 17.4 vs
         # 15.5 ms per cfg2 scene, profiles/r02_e2e_probe.txt)
-        self.zero_copy_d2h = os.environ.get("AL_D2H", "dma") == "kernel"
-        self.async_h2d = os.environ.get("AL_H2D", "blocking") == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
+        sw = switches.current()
+        self.zero_copy_d2h = sw.d2h == "kernel"
+        self.async_h2d = sw.h2d == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
         # threads that cast float64 IR tensors to float32 in the planner stage (0: upload the float64 bytes, cast on the device)
         # 16: 17.2-19.1 ms per cfg2 scene against 19.5-27.8 with 8 and 16.0 for float32 IRs (profiles/r03i_f64_threads_ab.txt)
-        self.cast_threads = int(os.environ.get("AL_CONVERT_THREADS", "16")) if os.environ.get("AL_F64_UPLOAD", "host") == "host" else 0
+        self.cast_threads = int(sw.convert_threads or 16) if sw.f64_upload == "host" else 0
         self._cast_pool = None
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):
@@ -116,10 +117,10 @@ class BatchDriver:
     def _plan(self, job: SceneJob, slot: int = 0):
         torch, r = self.torch, self.r
         c, n, l = job.irs.shape
-        pl = planning.plan_batch(job.specs, c, l, job.sample_rate)
+        pl = planning.plan_batch(job.specs, c, l, job.sample_rate, lib=r.lib)
         n_ev = len(job.clips)
         mix_plan = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n_ev,
-                                         pl.events["out_off"], list(range(n_ev)), job.duration, job.sample_rate, c)
+                                         pl.events["out_off"], list(range(n_ev)), job.duration, job.sample_rate, c, lib=r.lib)
         prev = self._slot_ready.get(slot)
         if prev is not None:
             prev.synchronize()   # the slot's pinned clip buffer may still be the source of an H2D copy in flight
@@ -611,14 +612,14 @@ def render_merged(renderer: engine.Renderer, jobs: Sequence[SceneJob]) -> List[n
     """Render the scenes of ``merge_jobs`` with one render launch sequence and one mixdown launch per scene."""
     specs, clips, irs, ranges = merge_jobs(jobs)
     c, l = irs.shape[0], irs.shape[2]
-    pl = planning.plan_batch(specs, c, l, jobs[0].sample_rate)
+    pl = planning.plan_batch(specs, c, l, jobs[0].sample_rate, lib=renderer.lib)
     res = renderer.render(pl, clips, irs)
     res.check_finite()
     out = []
     for job, (e0, n) in zip(jobs, ranges):
         mix = planning.plan_mixdown(job.starts, job.ends, [len(x) for x in job.clips], [c] * n,
                                     pl.events["out_off"][e0: e0 + n], list(range(e0, e0 + n)), job.duration,
-                                    job.sample_rate, c)
+                                    job.sample_rate, c, lib=renderer.lib)
         dev = renderer.mixdown(mix, res, job.ambience)
         out.append(renderer.mem.download(dev)[: c * mix.n_samples].reshape(c, mix.n_samples))
     return out

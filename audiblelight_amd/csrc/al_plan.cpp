@@ -289,6 +289,36 @@ int al_plan_chunk(const al_plan *p, int32_t event0, int32_t n_events, al_chunk *
   return AL_OK;
 }
 
+// al_batch.flags for a chunk of the plan: the dispatch policy the benchmarked path runs with, so that every host -- C, Python,
+// anything else -- reaches the same kernels from the same plan (include/audiblelight_hip.h, "Dispatch policy").  Measured rules:
+//   layout      B = 8192: split (every window as two 4096-point transforms, profiles/r02_split.txt: -5 % per scene);
+//               B = 16384: split + quad tiles (four 4096-point transforms, csrc/al_quad16.h: cfg5 13.9 instead of 17.0 ms);
+//               below 8192 the one-transform kernels (split is slower at B = 4096).
+//   accumulate  one-emitter events of batches with at most 21 partitions go through the capsule loop (k_spectral_mac_static*:
+//               -7 % on cfg2's accumulate, -14 % on cfg4's, -20..30 % at 13..17 partitions, profiles/r02_mac.txt, r03_p24_ab.txt);
+//               a chunk WITHOUT multi-emitter events does not launch the other accumulate kernels at all.
+int al_plan_batch_flags(const al_plan *p, const al_chunk *chunk, int32_t *flags) {
+  if (!p || !flags) return plan_fail(AL_E_BADARG, "null plan");
+  int32_t e0 = 0, n = (int32_t)p->events.size();
+  if (chunk) {
+    e0 = chunk->event0; n = chunk->n_events;
+    if (e0 < 0 || n < 0 || e0 + n > (int32_t)p->events.size()) return plan_fail(AL_E_BADARG, "bad chunk range");
+  }
+  int32_t f = 0;
+  if (p->log2_block == 13) f |= AL_FLAG_SPLIT_SPECTRA;
+  else if (p->log2_block == 14) f |= AL_FLAG_SPLIT_SPECTRA | AL_FLAG_QUAD_SPECTRA;
+  if (p->n_partitions() <= AL_STATIC_MAC_MAX_PARTITIONS) {
+    bool any_static = false, any_multi = false;
+    for (int32_t i = e0; i < e0 + n; ++i) {
+      any_static |= p->events[i].n_streams == 1;
+      any_multi |= p->events[i].n_streams > 1;
+    }
+    if (any_static) f |= AL_FLAG_STATIC_MAC | (any_multi ? 0 : AL_FLAG_ONLY_STATIC);
+  }
+  *flags = f;
+  return AL_OK;
+}
+
 // al_batch.emitter_parts for the whole plan.  Returns 1 and fills out[n_emitters] when the batch needs the table (some IR has
 // partitions no kept block hears, or -- fused_moving != 0 -- some IR column is heard only by sliding-window events and is
 // therefore transformed by k_moving_fused itself: 0 = "energy only"), 0 when every IR needs all its partitions (out untouched).

@@ -244,9 +244,14 @@ __device__ __forceinline__ void ir_spectra_quad16_body(const al_batch &b, float2
     if (p < p_live) {                                  // workgroup-uniform; else: no kept block hears it, its energy still counts
       float2 *out = reinterpret_cast<float2 *>(b.hspec) + (((int64_t)nz * b.n_capsules + c) * b.n_partitions + p) * B;
       quad16_forward_tiles<true>(h, h, out, s, tw, wt, tid, [&](auto half_c) { if (p + 1 < p1) request(p + 1, hn, decltype(half_c)::value); });
-    } else if (p + 1 < p1) {
-      request(p + 1, hn, 0);
-      request(p + 1, hn, 1);
+    } else {
+      if (p + 1 < p1) {
+        request(p + 1, hn, 0);
+        request(p + 1, hn, 1);
+      }
+      // a trimmed partition runs no transform, so nothing else separates thread 0's reads of `red` above from the other
+      // waves' writes for partition p + 1 (two trimmed partitions in a row of one run)
+      block_barrier<true>();
     }
     if (p + 1 < p1) {
 #pragma unroll

@@ -187,7 +187,12 @@ def prepare_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total
         raise ValueError(f"capsule sharding needs world_size <= capsules ({dist.get_world_size()} > {total_capsules})")
     if irs_local.shape[0] == 0:
         raise ValueError("this rank owns no capsule rows")
-    pl = planning.plan_batch(specs, irs_local.shape[0], irs_local.shape[2], sample_rate, log2_block=log2_block)
+    if log2_block is None:
+        # the planner's automatic block size depends on the batch's (capsule, block) row count: taken from the WHOLE scene, so that
+        # uneven shards cannot land on different sides of its threshold and every rank renders through the same transforms as a
+        # single-GPU render of the scene (rank 0's re-render check compares against exactly that)
+        log2_block = planning.plan_batch(specs, total_capsules, irs_local.shape[2], sample_rate, lib=renderer.lib).log2_block
+    pl = planning.plan_batch(specs, irs_local.shape[0], irs_local.shape[2], sample_rate, log2_block=log2_block, lib=renderer.lib)
     return renderer.prepare(pl, clips, irs_local)
 
 

@@ -6,20 +6,19 @@ all arithmetic happens in the kernels behind the C ABI (include/audiblelight_hip
 from __future__ import annotations
 
 import ctypes as ct
-import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from . import _hip
+from . import _hip, switches
 from .plan import SPARSE_MAX_PARTITIONS, BatchPlan, MixPlan
 
 
 def _debug_flags() -> int:
-    """Experimental kernel switches from the environment (AL_EXTRA_FLAGS), masked to the bits that select code paths
+    """Experimental kernel switches (AL_EXTRA_FLAGS, parsed once: switches.py), masked to the bits that select code paths
     with identical results; bit 0 (AL_FLAG_NO_IR_NORM) changes results and is never taken from it."""
-    return int(os.environ.get("AL_EXTRA_FLAGS", "0")) & _hip.DEBUG_FLAG_MASK
+    return switches.current().extra_flags & _hip.DEBUG_FLAG_MASK
 
 
 # ----------------------------------------------------------------------------- memory providers
@@ -116,7 +115,7 @@ class TorchMemory:
 
         flat = np.ascontiguousarray(arr).reshape(-1)
         n = flat.size
-        threads = int(os.environ.get("AL_CONVERT_THREADS", threads or 8))
+        threads = int(switches.current().convert_threads or threads or 8)
         if not hasattr(self, "_convert"):
             self._convert = dict(pool=None, threads=0, host=None, last=None)
         cv = self._convert
@@ -332,7 +331,7 @@ class Renderer:
         if irs.dtype not in (np.float32, np.float64):
             irs = irs.astype(np.float32)
         if host_cast is None:
-            host_cast = os.environ.get("AL_F64_UPLOAD", "host") == "host"
+            host_cast = switches.current().f64_upload == "host"
         if irs.dtype == np.float64 and host_cast and hasattr(self.mem, "upload_f64_as_f32"):
             raw = self.mem.upload_f64_as_f32(irs)        # converted on the host by a thread pool: half the PCIe bytes
             if lp == l:
@@ -361,7 +360,7 @@ class Renderer:
         if not (isinstance(irs, np.ndarray) and irs.ndim == 3 and irs.size > 0 and hasattr(mem, "upload_beside")):
             return None
         c, n, l = irs.shape
-        if irs.dtype == np.float32 and l % 4 == 0 and irs.nbytes >= int(os.environ.get("AL_BESIDE_MIN_BYTES", 8 << 20)) and not getattr(mem, "_no_beside", False):
+        if irs.dtype == np.float32 and l % 4 == 0 and irs.nbytes >= switches.current().beside_min_bytes and not getattr(mem, "_no_beside", False):
             try:
                 dev, arrived = mem.upload_beside(irs)
             except (OSError, AttributeError):      # no libamdhip64.so under that name for ctypes: the inline copy is always there
@@ -399,7 +398,7 @@ class Renderer:
         the budget -- ``AL_WORKSPACE_GB`` or 40 % of the HBM that is free right now -- else None (one chunk, the fast path:
         chunking does not reduce time, profiles/r01_chunk_sweep.txt).  The chunks reuse ONE workspace, so a scene of any
         number of events renders in bounded memory beside its inputs and outputs."""
-        budget = os.environ.get("AL_WORKSPACE_GB")
+        budget = switches.current().workspace_gb
         if budget is not None:
             budget = float(budget) * 1e9
         elif hasattr(self.mem, "free_bytes"):
@@ -446,14 +445,14 @@ class Renderer:
         if fold:
             tables += [np.array([src.prescale for src in sources], dtype=np.float32),
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
-        parts = plan.emitter_parts() if os.environ.get("AL_TRIM_PARTITIONS", "1") == "1" else None
+        sw = switches.current()      # parsed once per process (switches.py): nothing on this path reads the environment
+        parts = plan.emitter_parts() if sw.trim_partitions else None
         # EXPERIMENTAL, off by default (AL_FUSED_MOVING=1): sliding-window moving events through k_moving_fused (csrc/al_quad.h).
         # The accumulate transforms the IR partitions itself, their spectra are never written (cfg3: 36 -> 17 GB per scene) --
         # but one 512-thread workgroup per CU cannot overlap its load / transform / product phases, and it measures 8.8 ms
         # against 6.9 ms per cfg3 scene (profiles/r04b_cfg3_fused_first_version_ab.txt).  Needs the split + quad layout (B = 8192).
-        fused_static = os.environ.get("AL_FUSED", "0") == "1"
-        fuse_moving = (os.environ.get("AL_FUSED_MOVING", "0") == "1" and plan.log2_block == 13 and not fused_static
-                       and os.environ.get("AL_SPLIT", "1") == "1" and 1 <= P <= SPARSE_MAX_PARTITIONS)
+        fuse_moving = (sw.fused_moving and plan.log2_block == 13 and not sw.fused_static and sw.split is not False
+                       and 1 <= P <= SPARSE_MAX_PARTITIONS)
         fused_parts = plan.fused_moving_parts(parts) if fuse_moving else None
         fuse_moving = fused_parts is not None
         if fuse_moving:
@@ -492,46 +491,43 @@ class Renderer:
             yspec_block0=c["yspec_block0"], flags=(0 if normalize_irs else _hip.FLAG_NO_IR_NORM) | _debug_flags(),
             xspec_zero_block=x_blocks, hspec_zero_block=h_blocks, **lane_ptrs[i % lanes])
             for i, c in enumerate(chunks)]
-        # Split-layout transforms (csrc/al_split.h): every window as two half-size FFTs.  Default at B = 8192, where it is
-        # 5 % faster per scene (profiles/r02_split.txt); slower at B = 4096 and, as two 8192-point transforms, at 16384.  AL_SPLIT=0 / 1 forces it off / on.
-        fused = os.environ.get("AL_FUSED", "0") == "1"
-        # B = 16384: four 4096-point transforms per window (csrc/al_quad16.h; cfg5 13.9 instead of 17.0 ms per scene);
-        # AL_QUAD16=0 goes back to the one- / two-transform kernels of rounds 1-2.
-        quad16 = plan.log2_block == 14 and not fused and os.environ.get("AL_QUAD16", "1") == "1"
-        want_split = os.environ.get("AL_SPLIT", "1" if (plan.log2_block == 13 and not fused) or quad16 else "0") == "1"
-        if want_split and plan.log2_block >= 11:
-            for desc in descs:
-                desc.flags |= _hip.FLAG_SPLIT_SPECTRA
-                if fuse_moving:
-                    desc.flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
-                elif plan.log2_block == 13 and os.environ.get("AL_QUAD", "0") == "1":   # A/B + test switch: the quad layout alone
-                    desc.flags |= _hip.FLAG_QUAD_SPECTRA
-                elif quad16:
-                    desc.flags |= _hip.FLAG_QUAD_SPECTRA
-        # EXPERIMENTAL, off by default: accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes
-        # the Y round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
-        if fused and not (want_split and plan.log2_block >= 11):
-            for desc in descs:
-                if self.lib.call("al_fused_supported", ct.byref(desc)):
-                    desc.flags |= _hip.FLAG_FUSED_STATIC
-        # One-emitter (static) events: the capsule-loop accumulate (k_spectral_mac_static), default wherever the partitions
-        # fit its register tile (P <= 21: -7 % on cfg2's accumulate, -14 % on cfg4's, -20..30 % at P = 13..17, -9 % at 19..21;
-        # profiles/r02_mac.txt, r03_p24_ab.txt).
-        if os.environ.get("AL_STATIC_MAC", "1") == "1" and plan.n_partitions <= int(os.environ.get("AL_STATIC_MAC_MAX_P", "21")):
-            for desc in descs:
-                if desc.flags & _hip.FLAG_FUSED_STATIC:
-                    continue
-                ev = plan.events[desc.event0: desc.event0 + desc.n_events]
-                if (ev["n_streams"] == 1).any():
-                    desc.flags |= _hip.FLAG_STATIC_MAC
-                    if not (ev["n_streams"] > 1).any():
-                        desc.flags |= _hip.FLAG_ONLY_STATIC
+        # Which kernels run -- layout flags for the block size, accumulate flags for the chunk's event mix -- is the LIBRARY's
+        # decision (al_plan_batch_flags, csrc/al_plan.cpp): a C host gets the same dispatch from the same plan
+        # (tests/c_caller/render_planned.c).  The A/B switches of switches.py can force other paths.
+        for desc, chunk in zip(descs, chunks):
+            desc.flags |= plan.batch_flags(chunk, lib=self.lib)
+            if sw.forces_dispatch:
+                desc.flags = self._forced_dispatch(desc, plan, sw, fuse_moving)
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
             pre, mode = tabs[3], tabs[4]
             for desc in descs:
                 self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
             bufs["_clip_tables"] = (pre, mode)
         return PreparedBatch(self, plan, bufs, descs, lanes)
+
+    def _forced_dispatch(self, desc, plan: BatchPlan, sw, fuse_moving: bool) -> int:
+        """al_batch.flags with the A/B switches applied on top of the library's policy (tests and measurements only)."""
+        lb, P = plan.log2_block, plan.n_partitions
+        layout = _hip.FLAG_SPLIT_SPECTRA | _hip.FLAG_QUAD_SPECTRA
+        accumulate = _hip.FLAG_STATIC_MAC | _hip.FLAG_ONLY_STATIC
+        flags = desc.flags & ~layout
+        quad16 = lb == 14 and not sw.fused_static and sw.quad16      # AL_QUAD16=0: the one- / two-transform kernels at B = 16384
+        want_split = sw.split if sw.split is not None else ((lb == 13 and not sw.fused_static) or quad16)
+        if want_split and lb >= 11:
+            flags |= _hip.FLAG_SPLIT_SPECTRA
+            if fuse_moving:
+                flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
+            elif (lb == 13 and sw.quad) or quad16:
+                flags |= _hip.FLAG_QUAD_SPECTRA
+        # EXPERIMENTAL (AL_FUSED=1): accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes the Y
+        # round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
+        if sw.fused_static and not (want_split and lb >= 11):
+            desc.flags = flags
+            if self.lib.call("al_fused_supported", ct.byref(desc)):
+                flags |= _hip.FLAG_FUSED_STATIC
+        if not sw.static_mac or (sw.static_mac_max_p is not None and P > sw.static_mac_max_p) or (flags & _hip.FLAG_FUSED_STATIC):
+            flags &= ~accumulate
+        return flags
 
     def render(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                stages: Optional[Sequence[str]] = None, chunk_events: Optional[int] = None,

@@ -20,8 +20,11 @@ from . import _hip, config
 from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
 
 
-def _lib():
-    return _hip.get_library()
+def _lib(lib=None):
+    """The library a planning call goes through: the caller's (a Renderer built on its own Library -- host emulation, a
+    sanitizer build, AUDIBLELIGHT_HIP_LIB -- plans with THAT library, whose al_plan_last_error is the one that holds the
+    message) or the process default."""
+    return lib if lib is not None else _hip.get_library()
 
 
 def _copy(ptr, n, dtype):
@@ -42,7 +45,7 @@ def _round_up(x: int, m: int) -> int:
 
 
 def generate_interpolation_matrix(ir_times: np.ndarray, sr=config.SAMPLE_RATE, hop_size=config.HOP_SIZE,
-                                  n_frames: Optional[int] = None) -> np.ndarray:
+                                  n_frames: Optional[int] = None, lib=None) -> np.ndarray:
     """Linear cross-fade weights W[frame, ir] between consecutive IRs of a moving source.
 
     Same contract as the reference's ``generate_interpolation_matrix`` (synthesize.py:148-181):
@@ -62,7 +65,7 @@ def generate_interpolation_matrix(ir_times: np.ndarray, sr=config.SAMPLE_RATE, h
             weights[idx[keep], l] = 1.0 - up[keep]
             weights[idx[keep], l + 1] = up[keep]
         return weights
-    lib = _lib()
+    lib = _lib(lib)
     duration = float(times[-1])
     rows = lib.call("al_interpolation_rows", n, duration, float(sr), int(hop_size)) if n_frames is None else int(n_frames)
     weights = np.zeros((max(rows, 0), n), dtype=np.float64)
@@ -70,9 +73,9 @@ def generate_interpolation_matrix(ir_times: np.ndarray, sr=config.SAMPLE_RATE, h
     return weights
 
 
-def stft_frame_count(n_samples: int, hop_size: int = config.HOP_SIZE) -> int:
+def stft_frame_count(n_samples: int, hop_size: int = config.HOP_SIZE, lib=None) -> int:
     """Frames the reference STFT produces for n_samples (synthesize.py:123)."""
-    return int(_lib().call("al_stft_frame_count", int(n_samples), int(hop_size)))
+    return int(_lib(lib).call("al_stft_frame_count", int(n_samples), int(hop_size)))
 
 
 @dataclass
@@ -110,6 +113,7 @@ class BatchPlan:
     _sample_rate: float = 0.0
     _win: int = config.WIN_SIZE
     _handle: object = None               # _PlanHandle: the C planner's object (al_plan *), shared by copies of this plan
+    _library: object = None              # the _hip.Library that made (and frees) the handle; None = process default
 
     @property
     def block(self) -> int:
@@ -129,14 +133,14 @@ class BatchPlan:
             if self._specs is None:
                 raise ValueError("this BatchPlan was not made by plan_batch")
             self._handle = _PlanHandle(_create_c_plan(self._specs, self.n_capsules, self.ir_len, self._sample_rate, self.log2_block,
-                                                      self.hop, self._win, self.fft_size))
+                                                      self.hop, self._win, self.fft_size, _lib(self._library)), _lib(self._library))
         return self._handle.ptr
 
     def _parts(self, fused_moving: bool) -> Optional[np.ndarray]:
         if not len(self.events) or self.n_emitters <= 0:
             return None
         out = np.zeros(self.n_emitters, dtype=np.int32)
-        have = _lib().call("al_plan_emitter_parts", self._c_plan(), 1 if fused_moving else 0, out.ctypes.data)
+        have = _lib(self._library).call("al_plan_emitter_parts", self._c_plan(), 1 if fused_moving else 0, out.ctypes.data)
         return out if have == 1 else None
 
     def emitter_parts(self) -> Optional[np.ndarray]:
@@ -184,12 +188,24 @@ class BatchPlan:
         if n == 0:
             return [dict(event0=0, n_events=0, stream0=0, n_streams=0, emitter0=0, n_emitters=0, xspec_block0=0, xspec_blocks=0,
                          yspec_block0=0, yspec_blocks=0, max_blocks=0, max_nj=0)]
-        lib, handle, out = _lib(), self._c_plan(), []
+        lib, handle, out = _lib(self._library), self._c_plan(), []
         for e0 in range(0, n, max(step, 1)):
             ch = _hip.AlChunk()
             lib.call("al_plan_chunk", handle, e0, min(step, n - e0), ct.byref(ch))
             out.append({name: int(getattr(ch, name)) for name, _ in _hip.AlChunk._fields_})
         return out
+
+    def batch_flags(self, chunk: Optional[dict] = None, lib=None) -> int:
+        """al_batch.flags of a chunk (one of ``chunks()``; None = the whole plan): the library's dispatch policy --
+        layout flags for the block size, accumulate flags for the chunk's event mix (al_plan_batch_flags)."""
+        if not len(self.events):
+            return 0
+        flags = ct.c_int32(0)
+        ch = None
+        if chunk is not None:
+            ch = _hip.AlChunk(**{name: int(chunk[name]) for name, _ in _hip.AlChunk._fields_})
+        _lib(self._library).call("al_plan_batch_flags", self._c_plan(), ct.byref(ch) if ch is not None else None, ct.byref(flags))
+        return int(flags.value)
 
     def workspace_bytes(self) -> int:
         """Bytes of the spectra workspaces + statistics of the batch as one chunk (al_workspace_bytes)."""
@@ -198,28 +214,28 @@ class BatchPlan:
             + self.n_emitters * 4 + self.n_partials * 16
 
 
-def choose_log2_block(ir_len: int, max_clip: int) -> int:
+def choose_log2_block(ir_len: int, max_clip: int, lib=None) -> int:
     """Largest block that keeps two workgroups resident per CU (B = 8192: 68 KiB of LDS each),
     shrunk for short inputs so the zero padding of the last block stays small (al_choose_log2_block)."""
-    return int(_lib().call("al_choose_log2_block", int(ir_len), int(max_clip)))
+    return int(_lib(lib).call("al_choose_log2_block", int(ir_len), int(max_clip)))
 
 
 class _PlanHandle:
     """Owner of one ``al_plan *``: destroyed with the last BatchPlan that refers to it."""
 
-    def __init__(self, ptr):
-        self.ptr = ptr
+    def __init__(self, ptr, lib):
+        self.ptr, self.lib = ptr, lib
 
     def __del__(self):
         try:
             if self.ptr:
-                _lib().call("al_plan_destroy", self.ptr)
+                self.lib.call("al_plan_destroy", self.ptr)
         except Exception:  # noqa: BLE001 -- interpreter shutdown
             pass
         self.ptr = None
 
 
-def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size):
+def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size, lib):
     arr = (_hip.AlEventSpec * max(len(specs), 1))()
     for i, sp in enumerate(specs):
         arr[i] = _hip.AlEventSpec(n_samples=int(sp.n_samples), n_emitters=int(sp.n_emitters), emitter0=int(sp.emitter0),
@@ -227,7 +243,7 @@ def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win,
                                   stft_len=int(sp.stft_len or 0), duration=float(sp.duration if sp.duration is not None else 0.0))
     handle = ct.c_void_p()
     try:
-        _lib().call("al_plan_create", arr, len(specs), int(n_capsules), int(ir_len), float(sample_rate), int(log2_block or 0), int(hop),
+        lib.call("al_plan_create", arr, len(specs), int(n_capsules), int(ir_len), float(sample_rate), int(log2_block or 0), int(hop),
                     int(win), int(fft_size), ct.byref(handle))
     except _hip.HipError as exc:       # the reference's ValueErrors, with its messages (synthesize.py:565-584)
         raise ValueError(str(exc).split("): ", 1)[-1]) from None
@@ -236,15 +252,16 @@ def _create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win,
 
 def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_rate: float,
                log2_block: Optional[int] = None, hop: int = config.HOP_SIZE, win: int = config.WIN_SIZE,
-               fft_size: int = config.FFT_SIZE) -> BatchPlan:
-    """Build the kernel tables for a list of events sharing one IR tensor (one microphone): al_plan_create."""
+               fft_size: int = config.FFT_SIZE, lib=None) -> BatchPlan:
+    """Build the kernel tables for a list of events sharing one IR tensor (one microphone): al_plan_create.
+    ``lib``: the _hip.Library to plan with (a Renderer passes its own); default: the process-wide library."""
     if win != 2 * hop or fft_size < 2 * win - 1:
         raise ValueError("the HIP time-variant path needs win_size == 2*hop_size (sin^2 COLA) and fft_size >= 2*win_size-1")
     if log2_block is not None and not MIN_LOG2_BLOCK <= log2_block <= MAX_LOG2_BLOCK:
         raise ValueError(f"log2_block must be in [{MIN_LOG2_BLOCK}, {MAX_LOG2_BLOCK}]")
     specs = list(specs)
-    lib = _lib()
-    owner = _PlanHandle(_create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size))
+    library, lib = lib, _lib(lib)
+    owner = _PlanHandle(_create_c_plan(specs, n_capsules, ir_len, sample_rate, log2_block, hop, win, fft_size, lib), lib)
     handle = owner.ptr
     info = _hip.AlPlanInfo()
     lib.call("al_plan_get_info", handle, ct.byref(info))
@@ -256,7 +273,7 @@ def plan_batch(specs: Sequence[EventSpec], n_capsules: int, ir_len: int, sample_
                      events=events, streams=streams, wtab=wtab, audio_offsets=offsets, audio_floats=int(info.audio_floats),
                      spatial_floats=int(info.spatial_floats), xspec_blocks=int(info.xspec_blocks), yspec_blocks=int(info.yspec_blocks),
                      n_partials=int(info.n_partials), hop=hop, fft_size=fft_size, _specs=specs, _sample_rate=float(sample_rate), _win=win,
-                     _handle=owner)
+                     _handle=owner, _library=library)
 
 
 # ----------------------------------------------------------------------------- mixdown
@@ -287,7 +304,7 @@ def event_slot(scene_start: float, scene_end: float, sample_rate: float, n_scene
 
 def plan_mixdown(starts: Sequence[float], ends: Sequence[float], lens: Sequence[int], rows: Sequence[int],
                  src_offsets: Sequence[int], event_index: Sequence[int], duration: float, sample_rate: float,
-                 n_capsules: int, tile: int = 4096) -> MixPlan:
+                 n_capsules: int, tile: int = 4096, lib=None) -> MixPlan:
     """Slots and per-tile event lists (events keep insertion order inside every tile): al_plan_mixdown."""
     n = len(starts)
     a = np.ascontiguousarray(starts, dtype=np.float64)
@@ -296,7 +313,7 @@ def plan_mixdown(starts: Sequence[float], ends: Sequence[float], lens: Sequence[
     rw = np.ascontiguousarray(rows, dtype=np.int32)
     so = np.ascontiguousarray(src_offsets, dtype=np.int64)
     ei = np.ascontiguousarray(event_index, dtype=np.int32)
-    lib = _lib()
+    lib = _lib(lib)
     handle = ct.c_void_p()
     lib.call("al_plan_mixdown", a.ctypes.data, b.ctypes.data, la.ctypes.data, rw.ctypes.data, so.ctypes.data, ei.ctypes.data, n,
              float(duration), float(sample_rate), int(n_capsules), int(tile), ct.byref(handle))

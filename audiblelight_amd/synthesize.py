@@ -69,7 +69,7 @@ def time_invariant_convolution(audio: np.ndarray, ir: np.ndarray) -> np.ndarray:
     clip = np.zeros(n_out, dtype=np.float32)
     clip[: audio.shape[0]] = audio
     r = get_renderer()
-    pl = planning.plan_batch([planning.EventSpec(n_samples=n_out, n_emitters=1, snr=1.0)], n_ch, n_ir, 1.0)
+    pl = planning.plan_batch([planning.EventSpec(n_samples=n_out, n_emitters=1, snr=1.0)], n_ch, n_ir, 1.0, lib=r.lib)
     res = r.render(pl, [clip], np.ascontiguousarray(ir.T)[:, None, :], normalize_irs=False)
     return res.raw_spatial(0).astype(np.float64)
 
@@ -303,7 +303,7 @@ def _dry_batch(r: engine.Renderer, items, mic_alias: str, res: engine.RenderResu
     specs = [planning.EventSpec(n_samples=len(clip) + n_ir - 1, n_emitters=1, snr=1.0, emitter0=j)
              for j, (_, _, clip, _, _) in enumerate(todo)]
     clips = [np.concatenate([clip, np.zeros(n_ir - 1, np.float32)]) for _, _, clip, _, _ in todo]
-    pl = planning.plan_batch(specs, 1, n_ir, todo[0][0].sample_rate)
+    pl = planning.plan_batch(specs, 1, n_ir, todo[0][0].sample_rate, lib=r.lib)
     dry = r.prepare(pl, clips, np.stack([ir for _, ir, _, _, _ in todo])[None, :, :], normalize_irs=False)
     dry_res = dry.run(("al_forward_spectra", "al_emitter_gains", "al_spectral_mac", "al_block_synthesis"))
     for j, (event, _, _, index, em0) in enumerate(todo):
@@ -387,7 +387,7 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
             counter += n_emit
         if not specs:
             continue
-        pl = planning.plan_batch(specs, mic_ir.shape[0], mic_ir.shape[2], scene.sample_rate)
+        pl = planning.plan_batch(specs, mic_ir.shape[0], mic_ir.shape[2], scene.sample_rate, lib=r.lib)
         # Only ENQUEUED here: nothing below waits for the GPU.  The finite check of the reference (librosa.util.valid_audio,
         # synthesize.py:603) is made where the results first meet the host: in generate_scene_audio_from_events (one combined
         # download of every statistic of the scene) or on the first read of event.spatial_audio[mic].
@@ -446,7 +446,7 @@ def generate_scene_audio_from_events(scene) -> None:
             sub = [srcs[i] for i in idxs]
             mix = planning.plan_mixdown([events[i].scene_start for i in idxs], [events[i].scene_end for i in idxs],
                                         [s[2] for s in sub], [s[3] for s in sub], [s[1] for s in sub],
-                                        [s[5] for s in sub], scene.duration, scene.sample_rate, channels)
+                                        [s[5] for s in sub], scene.duration, scene.sample_rate, channels, lib=r.lib)
             for k in mix.skipped:
                 a, b = planning.event_slot(events[idxs[k]].scene_start, events[idxs[k]].scene_end, scene.sample_rate, duration)
                 logger.warning(f"Skipping event due to invalid slice: start={a}, end={b}")

@@ -159,8 +159,57 @@ def oracle_clip(scene, i):
     return orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(scene.clips[i], scene.gain_db[i]))).astype(np.float32)
 
 
-def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
-    """Time the float64 numpy/scipy oracle (kind "port") on a bounded sample of the same workload."""
+PARITY_TOL = 1e-4   # BASELINE.json north_star / SURVEY 8(d) "Parity metric": relative RMS AND max-abs / max|ref|, fp32 vs the fp64 oracle
+
+
+def parity_record(got, ref, events, note):
+    """Both halves of the contract's parity bound between a GPU scene buffer and the oracle's (C, T) float32 scene."""
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err2, ref2, worst, peak = 0.0, 0.0, 0.0, 0.0
+    for c in range(ref.shape[0]):          # row by row: no third scene-sized temporary in float64
+        r64, d = ref[c].astype(np.float64), got[c].astype(np.float64) - ref[c]
+        err2 += float(np.dot(d, d))
+        ref2 += float(np.dot(r64, r64))
+        worst, peak = max(worst, float(np.max(np.abs(d)))), max(peak, float(np.max(np.abs(r64))))
+    rel = (err2 / ref2) ** 0.5 if ref2 > 0 else float(err2 > 0)
+    mx = worst / peak if peak > 0 else float(worst > 0)
+    return {"rel_rms": rel, "max_abs_over_peak": mx, "rows": int(ref.shape[0]), "samples": int(ref.shape[1]), "events": int(events),
+            "tol": PARITY_TOL, "ok": bool(rel <= PARITY_TOL and mx <= PARITY_TOL and np.isfinite(rel) and np.isfinite(mx)),
+            "reference": "oracle/synth_oracle.py (float64 restatement of synthesize.py:613-677 + :314-401, pinned to the reference's goldens)",
+            "note": note}
+
+
+def oracle_partial_scene(scene, n_events, irs_of=None):
+    """The oracle's float32 (C, T) mix of the first `n_events` events of a synthetic scene, every IR of every event (no cap).
+    irs_of(e) -> (C, N_e, Lir) float array of event e's IR columns when the scene's tensor lives on the device."""
+    from oracle import synth_oracle as orc
+
+    spatials = []
+    for i in range(n_events):
+        sp = scene.specs[i]
+        h = irs_of(i) if irs_of is not None else scene.irs[:, sp.emitter0: sp.emitter0 + sp.n_emitters, :]
+        spatials.append(orc.render_event(oracle_clip(scene, i), np.asarray(h, dtype=np.float64), sp.snr, sp.ref_db, sp.is_moving,
+                                         sp.duration, scene.sr)["spatial"])
+    return orc.mix_scene(spatials, list(zip(scene.starts[:n_events], scene.ends[:n_events])), scene.duration, scene.sr,
+                         keep_padded=False)["scene"]
+
+
+def gpu_partial_scene(r, scene, pl, result, n_events):
+    """The GPU's mixdown of the first `n_events` events alone (no ambience) as a host (C, T) float32 array: what the oracle's
+    bounded sample is compared with when it does not cover the whole scene."""
+    from audiblelight_amd import plan as planning
+
+    idx = list(range(n_events))
+    mp = planning.plan_mixdown(scene.starts[:n_events], scene.ends[:n_events], [len(c) for c in scene.clips[:n_events]],
+                               [scene.n_capsules] * n_events, pl.events["out_off"][:n_events], idx, scene.duration, scene.sr,
+                               scene.n_capsules, lib=r.lib)
+    dev = r.prepare_mixdown(mp, result, []).run()
+    return r.mem.download(dev)[: scene.n_capsules * mp.n_samples].reshape(scene.n_capsules, mp.n_samples)
+
+
+def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8, keep_scene: bool = False):
+    """Time the float64 numpy/scipy oracle (kind "port") on a bounded sample of the same workload.  keep_scene: also return the
+    oracle's mixed (C, T) float32 scene of those events (None when the IR cap changed a moving event): (record, scene)."""
     from oracle import synth_oracle as orc
 
     t0 = time.perf_counter()
@@ -175,17 +224,21 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8):
         full_work += max(sp.n_emitters, 1)
     t_events = time.perf_counter() - t0
     t0 = time.perf_counter()
-    orc.mix_scene(spatials, list(zip(scene.starts[:n_events], scene.ends[:n_events])), scene.duration, scene.sr,
-                  keep_padded=True)
+    mixed = orc.mix_scene(spatials, list(zip(scene.starts[:n_events], scene.ends[:n_events])), scene.duration, scene.sr,
+                          keep_padded=True)
     t_mix = time.perf_counter() - t0
+    ref_scene = mixed["scene"]
+    del mixed, spatials
     total = t_events * full_work / max(work, 1) + t_mix * len(scene.specs) / n_events
     moving = any(sp.is_moving for sp in scene.specs)
-    return dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port", cpu_model=cpu_model(),
+    capped = any(sp.is_moving and sp.n_emitters > n_irs_cap for sp in scene.specs[:n_events])
+    rec = dict(value=scene.duration / total, unit="scene-seconds/s", cores=1, kind="port", cpu_model=cpu_model(),
                 extrapolated=n_events < len(scene.specs) or moving,
                 sample=f"{n_events} of {len(scene.specs)} events of one {scene.name} scene"
                        + (f" with {n_irs_cap} of {scene.specs[0].n_emitters} IRs each" if moving else "")
                        + f" (oracle render_event + mixdown incl. per-event padded copies): {t_events + t_mix:.1f} s measured"
                        + (", scaled linearly in events x IRs" if n_events < len(scene.specs) or moving else ""))
+    return (rec, None if capped else ref_scene) if keep_scene else rec
 
 
 def load_pmc_traffic(config: str, log2_block: int):
@@ -236,6 +289,12 @@ def dropin_leg(scene, renderer, n: int):
             "ms_per_scene_min_max": [round(min(calls) * 1e3, 2), round(max(calls) * 1e3, 2)],
             "note": "Scene.generate() per scene, synchronous: host float32 clips + IR tensor in (H2D), render, mixdown, "
                     "scene.audio out as a host ndarray (D2H); NOT the headline value"}
+
+
+def switches_in_effect() -> dict:
+    from audiblelight_amd import switches
+
+    return switches.current().non_default()
 
 
 def source_hash() -> str:
@@ -369,6 +428,10 @@ def main():
     ap.add_argument("--cpu-events", type=int, default=None,
                     help="events timed for the CPU baseline (0 = skip; default: the whole scene for cfg2 = 18 s on one core, "
                          "a bounded sample for the larger configurations)")
+    ap.add_argument("--parity-events", type=int, default=-1, metavar="N",
+                    help="events of the timed scene compared with the float64 oracle, all capsule rows x all samples (JSON `parity`; "
+                         "exit code 1 above 1e-4).  -1: the whole scene for cfg2 / cfg4 (the oracle scene of the cpu_baseline leg is "
+                         "reused), 1 event for cfg3, 2 for cfg5; 0: skip")
     ap.add_argument("--cpu-workers", type=int, default=-1, metavar="N",
                     help="also time the oracle on N host processes at once, one whole scene each (all-cores CPU figure; -1 = one per "
                          "PHYSICAL core, bounded by free memory; 0 = skip; skipped by itself under a profiler)")
@@ -508,7 +571,10 @@ def base_record(ctx, scene, pl, value, rep_s, steps, scaling, extra_config):
                    "ms_per_step_by_rank_last_repeat": None},
         "config": dict({"workload": scene.describe(), "scale": args.scale, "log2_block": pl.log2_block,
                         "chunk_events": args.chunk_events, "lanes": args.lanes, "hip_graph": bool(args.graph),
-                        "source_hash": source_hash()}, **extra_config),
+                        "source_hash": source_hash(),
+                        # every A/B switch of audiblelight_amd/switches.py that is NOT at its default ({} = the library's own
+                        # dispatch policy, al_plan_batch_flags, everywhere): a stray AL_* variable cannot change the timed path unseen
+                        "switches": switches_in_effect()}, **extra_config),
     }
 
 
@@ -555,6 +621,11 @@ def run_scene_per_rank_mode(ctx):
     instrumented = time.perf_counter() - t0
     by_rank = ctx["all_ranks"](own_s[-1] / args.steps * 1e3)
     batch.result().check_finite()
+    # parity of WHAT WAS TIMED: the scene buffer the timed steps wrote, on the host before any other leg runs
+    want_parity = rank == 0 and world == 1 and args.parity_events != 0
+    timed_scene_host = None
+    if want_parity and scene.ambience_beta is None:
+        timed_scene_host = np.array(r.mem.download(mix.scene)[: scene.n_capsules * mix_plan.n_samples].reshape(scene.n_capsules, -1))
     elapsed = float(np.median(rep_s))
     ms_per_step = elapsed / args.steps * 1e3
     if chunked:
@@ -586,6 +657,8 @@ def run_scene_per_rank_mode(ctx):
                        "hbm_bytes_per_launch_pmc": pmc}
     if args.other_configs and world == 1 and not emulate and args.config == "cfg2" and args.scale == 1.0:
         out["other_configs"] = other_configs_leg(ctx, r)
+        if any(not v.get("parity", {}).get("ok", True) for v in out["other_configs"].values()):
+            out["_failed"] = True
     if args.end_to_end > 0:
         out["end_to_end"] = end_to_end_leg(r, scene, args.end_to_end)
     if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
@@ -595,10 +668,29 @@ def run_scene_per_rank_mode(ctx):
                                                 lambda peer: rerender(ctx, r, peer))
         out["_failed"] = not ok
     if rank == 0 and world == 1:
+        ref_scene, ref_events = None, 0
         if args.cpu_events > 0:
-            out["cpu_baseline"] = cpu_baseline(scene, min(args.cpu_events, n_ev))
+            ref_events = min(args.cpu_events, n_ev)
+            out["cpu_baseline"], ref_scene = cpu_baseline(scene, ref_events, keep_scene=True)
         if ctx["all_cores"] is not None:
             out["cpu_baseline_all_cores"] = ctx["all_cores"]
+        if want_parity:
+            # the oracle's scene from the cpu_baseline leg IS the reference (no second CPU pass) whenever that leg rendered the
+            # events the parity leg asks for with every IR; else the oracle renders `parity_events` events here
+            n_par = n_ev if args.parity_events < 0 else min(args.parity_events, n_ev)
+            if args.parity_events < 0 and args.config != "cfg2":
+                n_par = min({"cfg3": 1, "cfg4": n_ev, "cfg5": 2}.get(args.config, n_ev), n_ev)
+            if ref_scene is None or ref_events != n_par:
+                ref_scene = oracle_partial_scene(scene, n_par)
+            if n_par == n_ev and timed_scene_host is not None:
+                got, note = timed_scene_host, "the (C, T) scene buffer the timed steps wrote vs the oracle's mix of ALL events"
+            else:
+                got = gpu_partial_scene(r, scene, pl, batch.result(), n_par)
+                note = (f"GPU mixdown of the first {n_par} of {n_ev} events of the timed render (no ambience) vs the oracle's mix of the "
+                        "same events, every IR, all rows")
+            out["parity"] = parity_record(got, ref_scene, n_par, note)
+            if not out["parity"]["ok"]:
+                out["_failed"] = True
     return out
 
 
@@ -657,6 +749,23 @@ def other_configs_leg(ctx, r):
                      "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                      "inputs": "clips drawn on the host, IR tensor on the device (same law)",
                      "setup_s": None}
+        if args.parity_events != 0:
+            # a bounded number of events of THIS render against the oracle, every IR, all capsule rows x all scene samples
+            n_par = {"cfg3": 1, "cfg4": 4, "cfg5": 2}[name]
+            c_, n_, l_ = scene.ir_shape
+            ir_view = scene.irs_dev.reshape(c_, n_, l_)
+
+            def irs_of(e, ir_view=ir_view, scene=scene):
+                sp = scene.specs[e]
+                return ir_view[:, sp.emitter0: sp.emitter0 + sp.n_emitters, :].cpu().numpy()
+
+            t_par = time.perf_counter()
+            ref = oracle_partial_scene(scene, n_par, irs_of)
+            got = gpu_partial_scene(r, scene, pl, batch.result(), n_par)
+            out[name]["parity"] = parity_record(got, ref, n_par, f"GPU mixdown of the first {n_par} of {len(scene.specs)} events of the timed "
+                                                "render (no ambience) vs the oracle's mix of the same events, every IR, all rows")
+            out[name]["parity"]["seconds"] = round(time.perf_counter() - t_par, 1)
+            del ref, got, ir_view
         del batch, mix, scene, ev
         torch.cuda.empty_cache()
         out[name]["setup_s"] = round(time.perf_counter() - t_in - 4 * steps * ms * 1e-3, 1)

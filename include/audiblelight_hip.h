@@ -29,8 +29,9 @@ extern "C" {
  * al_mix grew fields in version 2: clip_scale, xspec/hspec_zero_block, ambience, ambience_scale; version 3 puts
  * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread;
  * version 4 appends al_batch.emitter_parts; version 5 adds the host-side planner (al_plan_*, al_workspace_bytes,
- * al_plan_mixdown) and the AL_FLAG_QUAD_SPECTRA / AL_FLAG_FUSED_MOVING path: no struct changed). */
-#define AL_ABI_VERSION 5
+ * al_plan_mixdown) and the AL_FLAG_QUAD_SPECTRA / AL_FLAG_FUSED_MOVING path: no struct changed; version 6 adds
+ * al_plan_batch_flags -- the dispatch policy (layout + accumulate flags per chunk) moves from the hosts into the library). */
+#define AL_ABI_VERSION 6
 
 #define AL_OK 0
 #define AL_E_BADARG (-1)
@@ -73,6 +74,7 @@ extern "C" {
 
 #define AL_SPARSE_MAX_NJ 6          /* longest stream (in blocks) the sliding-window accumulate accepts */
 #define AL_SPARSE_MAX_PARTITIONS 24 /* most IR partitions it accepts */
+#define AL_STATIC_MAC_MAX_PARTITIONS 21 /* most IR partitions the capsule-loop accumulate (AL_FLAG_STATIC_MAC) takes */
 
 #define AL_MIN_LOG2_BLOCK 10
 #define AL_MAX_LOG2_BLOCK 14
@@ -439,6 +441,13 @@ int al_plan_chunk(const al_plan *plan, int32_t event0, int32_t n_events, al_chun
 int64_t al_workspace_bytes(const al_plan *plan);
 /* al_batch.emitter_parts: returns 1 and fills out[n_emitters] if the batch needs the table, 0 if every IR needs all partitions */
 int al_plan_emitter_parts(const al_plan *plan, int32_t fused_moving, int32_t *out);
+/* Dispatch policy: al_batch.flags for a chunk of the plan (chunk == NULL: the whole plan as one batch) -- the layout flags for
+ * the plan's block size (AL_FLAG_SPLIT_SPECTRA at 8192, + AL_FLAG_QUAD_SPECTRA at 16384) and the accumulate flags for the chunk's
+ * event mix (AL_FLAG_STATIC_MAC when it has one-emitter events and at most AL_STATIC_MAC_MAX_PARTITIONS partitions, +
+ * AL_FLAG_ONLY_STATIC when it has no multi-emitter event).  This IS the configuration bench.py times: a host that ORs the result
+ * into al_batch.flags (plus AL_FLAG_NO_IR_NORM where it applies) runs the same kernels as audiblelight_amd/engine.py, which
+ * calls this too; al_spectral_mac_variant on the finished descriptor tells which. */
+int al_plan_batch_flags(const al_plan *plan, const al_chunk *chunk, int32_t *flags);
 int al_plan_mixdown(const double *starts, const double *ends, const int32_t *lens, const int32_t *rows, const int64_t *src_offsets,
                     const int32_t *event_index, int32_t n, double duration, double sample_rate, int32_t n_capsules, int32_t tile,
                     al_mix_plan **out);

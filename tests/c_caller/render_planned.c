@@ -137,12 +137,14 @@ int main(int argc, char **argv) {
   HIP_OK(hipMemsetAsync((char *)b.hspec + (size_t)h_max * blk, 0, blk, stream));
   HIP_OK(hipMemsetAsync((char *)b.xspec + (size_t)x_max * blk, 0, blk, stream));
   b.hspec_zero_block = (int32_t)h_max, b.xspec_zero_block = (int32_t)x_max;
-  /* the layouts the transforms are fastest in: split at B = 8192, quad tiles at B = 16384 (include/audiblelight_hip.h) */
-  int32_t flags = info.log2_block == 13 ? AL_FLAG_SPLIT_SPECTRA : info.log2_block == 14 ? (AL_FLAG_SPLIT_SPECTRA | AL_FLAG_QUAD_SPECTRA) : 0;
+  /* the dispatch policy is the library's (al_plan_batch_flags): layout flags for the block size, accumulate flags per chunk's
+   * event mix -- this host decides nothing; `extra` is only the opt-in experimental moving kernel this test can ask for */
+  int32_t whole = 0, extra = 0;
+  AL_CALL(al_plan_batch_flags(plan, NULL, &whole));
   int fused = 0;
   if (want_fused && info.log2_block == 13 && info.max_nj_sliding >= 1 && info.max_nj_sliding <= 5) {
-    b.flags = flags | AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5;
-    if (al_moving_fused_supported(&b)) fused = 1, flags = b.flags | AL_FLAG_FUSED_MOVING;
+    b.flags = whole | AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5;
+    if (al_moving_fused_supported(&b)) fused = 1, extra = AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5 | AL_FLAG_FUSED_MOVING;
   }
   int32_t *parts = malloc(4 * (size_t)(info.n_emitters + 1));
   const int have_parts = al_plan_emitter_parts(plan, fused, parts);
@@ -155,7 +157,9 @@ int main(int argc, char **argv) {
     AL_CALL(al_plan_chunk(plan, e0, e0 + step <= E ? step : E - e0, &ch));
     b.event0 = ch.event0, b.n_events = ch.n_events, b.stream0 = ch.stream0, b.n_streams = ch.n_streams;
     b.emitter0 = ch.emitter0, b.n_emitters = ch.n_emitters, b.xspec_block0 = ch.xspec_block0, b.yspec_block0 = ch.yspec_block0;
-    b.max_blocks = ch.max_blocks, b.max_nj = ch.max_nj, b.flags = flags;
+    int32_t policy = 0;
+    AL_CALL(al_plan_batch_flags(plan, &ch, &policy));
+    b.max_blocks = ch.max_blocks, b.max_nj = ch.max_nj, b.flags = policy | extra;
     AL_CALL(al_render_batch(&b, stream));
   }
 
@@ -208,11 +212,16 @@ int main(int argc, char **argv) {
   for (int e = 0; e < E; ++e) fwrite(h_spatial + ev[e].out_off, 4, (size_t)C * specs[e].n_samples, f);
   fwrite(h_scene, 4, (size_t)C * T, f);
   fclose(f);
+  /* which accumulate kernels the whole plan as ONE batch reaches under the library's policy (the test compares these codes with
+   * what audiblelight_amd/engine.py gets from the same plan) */
   int32_t sc = 0, mc = 0;
-  b.event0 = 0, b.n_events = E;
-  al_spectral_mac_variant(&b, &sc, &mc);
-  printf("rendered %d events x %d capsules in %d chunk(s), B = %d, P = %d, fused_moving = %d, moving_code = %d, skipped = %d\n", E, C, n_chunks, B, P,
-         fused, mc, mt.n_skipped);
+  al_chunk all;
+  AL_CALL(al_plan_chunk(plan, 0, E, &all));
+  b.event0 = 0, b.n_events = E, b.stream0 = all.stream0, b.n_streams = all.n_streams, b.emitter0 = all.emitter0, b.n_emitters = all.n_emitters;
+  b.max_blocks = all.max_blocks, b.max_nj = all.max_nj, b.flags = whole | extra;
+  AL_CALL(al_spectral_mac_variant(&b, &sc, &mc));
+  printf("rendered %d events x %d capsules in %d chunk(s), B = %d, P = %d, fused_moving = %d, moving_code = %d, static_code = %d, flags = %d, skipped = %d\n",
+         E, C, n_chunks, B, P, fused, mc, sc, whole | extra, mt.n_skipped);
   al_mix_plan_destroy(mp);
   al_plan_destroy(plan);
   return 0;

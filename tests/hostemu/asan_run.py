@@ -1,6 +1,17 @@
 import sys, numpy as np
 sys.path.insert(0, "/root/repo")
-from audiblelight_amd import _hip, engine, plan as planning
+import os
+from audiblelight_amd import _hip, engine, plan as planning, switches
+
+
+def setenv(name, value):     # the package parses its AL_* switches once per process (audiblelight_amd/switches.py)
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = value
+    switches.reload()
+
+
 from tests import hostemu
 _hip._default = _hip.Library(sys.argv[1])     # the planner (csrc/al_plan.cpp) runs from the sanitized build too
 r = engine.Renderer(lib=_hip._default, memory=hostemu.NumpyMemory())
@@ -21,7 +32,7 @@ print("asan run ok", float(np.abs(scene[: C * mix.n_samples]).sum()), res.scales
 # zero row), rows at odd offsets (shifted-pair stores), the split spectra layout, the frame encoder's 16-byte store paths
 import ctypes as ct, os
 for lb, split in ((10, "0"), (11, "1")):
-    os.environ["AL_SPLIT"] = split
+    setenv("AL_SPLIT", split)
     B = 1 << lb
     La, Lir, C = 26 * B + 1, 13 * B - 5, 2
     clips = [rng.standard_normal(La - 2 * e).astype(np.float32) for e in range(2)]
@@ -47,7 +58,7 @@ print("asan run ok: round-2 kernels")
 # round 3 kernels: the LDS-DMA capsule loop ran above (13 partitions -> accumulate code ...04; the DMA pieces are plain copies
 # under emulation); here three units of 7 with the window ends in LDS, the device-side normal draws, the seeded noise
 # transform (even and odd length), the per-channel ambience multipliers and the row-wise axpy
-os.environ["AL_SPLIT"] = "0"
+setenv("AL_SPLIT", "0")
 B, C = 1024, 2
 clips = [rng.standard_normal(14 * B + 3).astype(np.float32)]
 irs = (rng.standard_normal((C, 1, 20 * B - 9)) * np.exp(-np.arange(20 * B - 9) / (4.0 * B))).astype(np.float32)
@@ -74,8 +85,8 @@ print("asan run ok: round-3 kernels")
 # al_plan_mixdown from the sanitized library); here the quad spectrum layout and k_moving_fused (csrc/al_quad.h) at B = 8192:
 # two passes over 10 partitions with a ragged last one, streams of 5 and of 6 blocks, tile 0's real-FFT unpacking, and a static
 # event beside it in the quad layout
-os.environ["AL_SPLIT"] = "1"
-os.environ["AL_FUSED_MOVING"] = "1"
+setenv("AL_SPLIT", "1")
+setenv("AL_FUSED_MOVING", "1")
 B = 8192
 for n_irs, k_mult in ((6, 7.3), (4, 6.1)):
     La, Lir = int(k_mult * B), int(9.3 * B)
@@ -90,7 +101,7 @@ for n_irs, k_mult in ((6, 7.3), (4, 6.1)):
     res = batch.run()
     res.check_finite()
     print("asan run ok: fused moving accumulate, code", m_code.value, float(np.abs(res.spatial_audio(0)).sum()))
-del os.environ["AL_FUSED_MOVING"]
+setenv("AL_FUSED_MOVING", None)
 # the quad-tile transforms at B = 16384 (csrc/al_quad16.h): a run of five IR partitions with a ragged last one (the prefetch
 # hand-over), interior and edge signal windows, the rolled general signal path (moving event), the four-tile inverse
 B = 16384
@@ -101,11 +112,11 @@ specs = [planning.EventSpec(n_samples=La, n_emitters=1, snr=10.0, emitter0=0),
          planning.EventSpec(n_samples=len(clips[1]), n_emitters=3, snr=12.0, emitter0=1, is_moving=True, duration=len(clips[1]) / 48000)]
 pl = planning.plan_batch(specs, 2, Lir, 48000, log2_block=14)
 for run_len in (0, 3):          # a batch this small gets runs of one partition; AL_FLAG_IR_RUN(3): 3 + 2, the hand-over between partitions
-    os.environ["AL_EXTRA_FLAGS"] = str(run_len << 24)
+    setenv("AL_EXTRA_FLAGS", str(run_len << 24))
     batch = r.prepare(pl, clips, irs)
     assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA
     res = batch.run()
     res.check_finite()
     print("asan run ok: quad-tile transforms at B = 16384, runs of", run_len or 1, float(np.abs(res.spatial_audio(0)).sum()))
-del os.environ["AL_EXTRA_FLAGS"]
+setenv("AL_EXTRA_FLAGS", None)
 print("asan run ok: round-4 kernels")

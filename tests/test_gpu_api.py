@@ -2,6 +2,8 @@
 through the gfx950 library (audiblelight_amd/csrc/libaudiblelight_hip.so) instead of the host emulation."""
 import pytest
 
+from tests.conftest import set_switch
+
 from tests import test_hostemu_api as scenarios
 
 pytestmark = pytest.mark.gpu
@@ -83,7 +85,7 @@ def test_background_ir_upload_equals_inline_upload_on_any_stream(gpu_renderer, m
         out = sc.generate()
         return {k: np.array(v) for k, v in out.items()}
 
-    monkeypatch.setenv("AL_BESIDE_MIN_BYTES", "0")       # default: tensors of 8 MiB and more
+    set_switch(monkeypatch, "AL_BESIDE_MIN_BYTES", "0")       # default: tensors of 8 MiB and more
     calls = []
     real = engine.Renderer.upload_irs_beside
 

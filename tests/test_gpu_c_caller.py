@@ -117,3 +117,61 @@ def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fus
                         keep_padded=False)["scene"]
     for c in range(C):
         assert_parity(scene[c], ref[c], TOL, what=("scene", c))
+
+
+def test_c_host_reaches_the_benchmarked_accumulate(tmp_path):
+    """The dispatch policy lives behind the C ABI (al_plan_batch_flags): on a batch in cfg2's regime (static events, 12
+    partitions of 8192, clips of 13..24 blocks) the C host of render_planned.c -- which sets no flag of its own -- reaches the
+    same kernels as audiblelight_amd/engine.py does from the same plan: k_spectral_mac_static<12,12,2> (code 3121202), the
+    accumulate bench.py times, with the split layout; and it renders what the oracle renders."""
+    if not os.path.exists(PLANNED):
+        import __graft_entry__
+
+        __graft_entry__.build_c_caller()
+    import ctypes as ct
+
+    from audiblelight_amd import _hip, engine, plan as planning
+
+    B = 8192
+    rng = np.random.default_rng(7)
+    C, sr, ref_db, lir = 2, 48000.0, -65.0, 12 * B - 5
+    lens = [14 * B + 3, 20 * B - 1, 23 * B + 77]
+    duration = 30 * B / sr
+    events = [dict(n=n, snr=float(rng.uniform(5, 30)), start=float(rng.uniform(0, duration - n / sr))) for n in lens]
+    clips = [rng.standard_normal(n).astype(np.float32) for n in lens]
+    clips = [c / np.abs(c).max() for c in clips]
+    irs = (rng.standard_normal((C, len(lens), lir)) * np.exp(-np.arange(lir) / (lir / 5.0))).astype(np.float32)
+    T = round(duration * sr)
+    src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(src, "wb") as f:
+        np.array([C, len(events), len(events), lir, 0, 0, 0, 0], dtype=np.int32).tofile(f)      # log2_block 0: the library's choice
+        np.array([ref_db, sr, duration, 0.0], dtype=np.float32).tofile(f)
+        for i, ev in enumerate(events):
+            np.array([ev["n"], 1, i, 0], dtype=np.int32).tofile(f)
+            np.array([ev["snr"], ev["start"]], dtype=np.float32).tofile(f)
+        for c in clips:
+            c.tofile(f)
+        irs.tofile(f)
+    run = subprocess.run([PLANNED, str(src), str(dst)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr + run.stdout
+    want_flags = _hip.FLAG_SPLIT_SPECTRA | _hip.FLAG_STATIC_MAC | _hip.FLAG_ONLY_STATIC
+    assert "B = 8192, P = 12" in run.stdout and "static_code = 3121202" in run.stdout and f"flags = {want_flags}," in run.stdout, run.stdout
+    # the Python host on the same plan: same flags, same instantiation
+    specs = [planning.EventSpec(n_samples=ev["n"], n_emitters=1, snr=ev["snr"], emitter0=i, ref_db=ref_db) for i, ev in enumerate(events)]
+    r = engine.Renderer()
+    batch = r.prepare(planning.plan_batch(specs, C, lir, sr, lib=r.lib), clips, irs)
+    sc, mc = ct.c_int32(), ct.c_int32()
+    r.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(sc), ct.byref(mc))
+    assert (sc.value, batch.descs[0].flags & ~_hip.DEBUG_FLAG_MASK) == (3121202, want_flags)
+    out = np.fromfile(dst, dtype=np.float32)
+    E = len(events)
+    scale, at, want_spatial = out[:E], E, []
+    for i, ev in enumerate(events):
+        got = out[at: at + C * ev["n"]].reshape(C, ev["n"]).astype(np.float64) * float(scale[i])
+        at += C * ev["n"]
+        want = orc.render_event(clips[i], irs[:, [i], :].astype(np.float64), float(np.float32(ev["snr"])), ref_db=ref_db, sr=sr)["spatial"]
+        assert_parity(got, want, TOL, what=i)
+        want_spatial.append(want)
+    slots = [(float(np.float32(ev["start"])), float(np.float32(ev["start"])) + ev["n"] / sr) for ev in events]
+    ref = orc.mix_scene(want_spatial, slots, duration, sr, keep_padded=False)["scene"]
+    assert_parity(out[at:].reshape(C, T), ref, TOL)

@@ -11,7 +11,7 @@ import pytest
 from scipy.signal import fftconvolve
 
 from oracle import synth_oracle as orc
-from tests.conftest import assert_parity, rel_rms
+from tests.conftest import assert_parity, rel_rms, set_switch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -84,7 +84,7 @@ def test_cfg3_full_size_moving_sources(gpu, monkeypatch, fused):
     from audiblelight_amd import plan as planning
     from tests import mac_regimes as mr
 
-    monkeypatch.setenv("AL_FUSED_MOVING", fused)
+    set_switch(monkeypatch, "AL_FUSED_MOVING", fused)
     sc = _cfg3_scene()
     assert sc.irs.shape == (32, 16 * 32, 96000) and len(sc.clips) == 16 and len(sc.clips[0]) == 372000
     pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)

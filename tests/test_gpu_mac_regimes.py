@@ -6,6 +6,8 @@ k_spectral_mac_moving at P = 12 with 32 IRs per event at B = 8192 (cfg3).  Refer
 """
 import pytest
 
+from tests.conftest import set_switch
+
 from tests import mac_regimes as mr
 
 pytestmark = pytest.mark.gpu
@@ -25,8 +27,8 @@ def gpu():
 def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch):
     """The tile kernels (k_spectral_mac + k_block_synthesis): AL_STATIC_MAC=0 keeps their dispatch branches reachable for
     static events (they are the default for more than 12 partitions and for multi-emitter events)."""
-    monkeypatch.setenv("AL_STATIC_MAC", "0")
-    monkeypatch.delenv("AL_FUSED", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", "0")
+    set_switch(monkeypatch, "AL_FUSED", None)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block >= 13))   # 14: csrc/al_quad16.h
 
 
@@ -36,8 +38,8 @@ def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_
     """k_spectral_mac_static / _static_lds / _static_glds (default for one-emitter events with at most 21 partitions): EVERY
     instantiation -- partition counts 1..21 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
     the capsule-range split of small batches; every row against the oracle, the instantiation asserted."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_FUSED", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_FUSED", None)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
 
 
@@ -47,9 +49,9 @@ def test_static_capsule_loop_glds_kernel(gpu, monkeypatch, log2_block, name, cod
     """k_spectral_mac_static_glds (partition spectra into the LDS ring by LDS-DMA, counted s_waitcnt) for at most 12 partitions,
     where it is an A/B switch (13..24 partitions take it by default: test_static_capsule_loop_kernel): every partition count
     1..12, second k-tile full / ragged / idle, one and several workgroups per (event, bin tile); every row against the oracle."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_FUSED", raising=False)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_FUSED", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(1 << 14))
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
 
 
@@ -57,8 +59,8 @@ def test_static_capsule_loop_glds_kernel(gpu, monkeypatch, log2_block, name, cod
 def test_static_capsule_loop_without_zero_block(gpu, monkeypatch, name, code, k_mult, p_mult, C, E):
     """13..16 partitions for a batch without an all-zero spectrum block (hspec_zero_block = -1, e.g. a C host that keeps
     none): the register-staged two-unit kernel k_spectral_mac_static_lds<12,{7,8},2> instead of the LDS-DMA one."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
     mr.run_static_case(gpu, 13, code, k_mult, p_mult, C=C, E=E, zero_block=False)
 
 
@@ -67,7 +69,7 @@ def test_fused_static_regimes(gpu, name, code, k_mult, p_mult, monkeypatch):
     """k_mac_synthesis (B = 8192, opt-in with AL_FUSED=1: experimental, see profiles/r02_fused.txt): k-tiles of 4 blocks
     with ragged last tiles, one and two partition tiles (PT = 6 / 12, full and ragged instantiations), clips shorter and
     longer than the IR; every row against the oracle."""
-    monkeypatch.setenv("AL_FUSED", "1")
+    set_switch(monkeypatch, "AL_FUSED", "1")
     mr.run_static_case(gpu, 13, code, k_mult, p_mult, expect_fused=True, expect_split=False)
 
 
@@ -79,7 +81,7 @@ def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
     from audiblelight_amd import plan as planning
     from oracle import synth_oracle as orc
 
-    monkeypatch.setenv("AL_FUSED", "1")
+    set_switch(monkeypatch, "AL_FUSED", "1")
     rng = np.random.default_rng(31)
     sr, C, L, B = 48000, 3, 5 * 8192 + 100, 8192
     specs, clips, irs, col = [], [], [], 0
@@ -106,7 +108,7 @@ def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
                          ids=["P5", "P12", "P13", "P24", "P25_tile_kernel"])
 def test_moving_regimes(gpu, monkeypatch, log2_block, p_mult, expect):
     """The sliding-window accumulate over stored IR spectra (k_spectral_mac_moving): the default at every block size."""
-    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
+    set_switch(monkeypatch, "AL_FUSED_MOVING", None)
     mr.run_moving_case(gpu, log2_block, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect)
 
 
@@ -119,7 +121,7 @@ def test_fused_moving_regimes(gpu, monkeypatch, p_mult, n_irs, k_mult, expect):
     itself in the quad layout, no IR spectrum is written (the poisoned workspace stays poisoned).  Both instantiations (streams
     of at most 5 / 6 blocks), one, two and three passes over the partitions with a ragged last pass, ragged last partition,
     IRs whose late partitions reach no kept block; every row against the oracle."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "1")
+    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
     mr.run_moving_case(gpu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=3, E=2)
 
 
@@ -134,8 +136,8 @@ def test_transform_layouts(gpu, monkeypatch, log2_block, split):
     from audiblelight_amd import plan as planning
     from oracle import synth_oracle as orc
 
-    monkeypatch.setenv("AL_SPLIT", split)
-    monkeypatch.setenv("AL_QUAD16", "0")       # B = 16384 here: two 8192-point transforms (the quad tiles have their own tests below)
+    set_switch(monkeypatch, "AL_SPLIT", split)
+    set_switch(monkeypatch, "AL_QUAD16", "0")       # B = 16384 here: two 8192-point transforms (the quad tiles have their own tests below)
     B = 1 << log2_block
     rng = np.random.default_rng(40 + log2_block)
     sr, C, L = 48000, 3, int(2.3 * B) + 7
@@ -161,8 +163,8 @@ def test_default_layout_per_block_size(gpu, monkeypatch):
     from audiblelight_amd import plan as planning
     import numpy as np
 
-    monkeypatch.delenv("AL_SPLIT", raising=False)
-    monkeypatch.delenv("AL_FUSED", raising=False)
+    set_switch(monkeypatch, "AL_SPLIT", None)
+    set_switch(monkeypatch, "AL_FUSED", None)
     for lb in (10, 12, 13, 14):
         pl = planning.plan_batch([planning.EventSpec(n_samples=3000, n_emitters=1, snr=5.0)], 2, 500, 48000, log2_block=lb)
         batch = gpu.prepare(pl, [np.zeros(3000, np.float32)], np.zeros((2, 1, 500), np.float32))
@@ -173,11 +175,11 @@ def test_quad_layout_alone(gpu, monkeypatch):
     """The quad slot maps of the split kernels (QuadSlots, csrc/al_fft.h; AL_QUAD=1) WITHOUT the fused kernel: static events through
     the capsule loop at cfg2's regime and moving events through k_spectral_mac_moving over stored spectra in that layout (the IR,
     signal and output spectra all permuted the same way; the accumulate must not notice), every row against the oracle."""
-    monkeypatch.setenv("AL_QUAD", "1")
-    monkeypatch.delenv("AL_FUSED_MOVING", raising=False)
+    set_switch(monkeypatch, "AL_QUAD", "1")
+    set_switch(monkeypatch, "AL_FUSED_MOVING", None)
     res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=3, E=2, expect_fused=False, expect_split=True, expect_quad=True)
     assert res.plan.n_partitions == 12
-    monkeypatch.setenv("AL_TRIM_PARTITIONS", "1")
+    set_switch(monkeypatch, "AL_TRIM_PARTITIONS", "1")
     res = mr.run_moving_case(gpu, 13, 11.72, n_irs=24, k_mult=30.1, expect_moving=612, C=3, E=2)
     assert res.plan.log2_block == 13
 
@@ -191,7 +193,7 @@ def test_cfg3_regime_all_rows(gpu):
 
 def test_cfg3_regime_all_rows_fused_kernel(gpu, monkeypatch):
     """The same through k_moving_fused<5,8> (AL_FUSED_MOVING=1: the IR partitions transformed inside the accumulate)."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "1")
+    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
     res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=10508, C=4, E=2)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
 
@@ -211,14 +213,14 @@ def test_cfg2_regime_all_rows(gpu):
 
 def test_cfg2_regime_all_rows_tile_kernels(gpu, monkeypatch):
     """The same through k_spectral_mac<12,12,2,KSPLIT> and the one-transform FFT kernels (round 1's path)."""
-    monkeypatch.setenv("AL_STATIC_MAC", "0")
-    monkeypatch.setenv("AL_SPLIT", "0")
+    set_switch(monkeypatch, "AL_STATIC_MAC", "0")
+    set_switch(monkeypatch, "AL_SPLIT", "0")
     mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False, expect_split=False)
 
 
 def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
     """The same through the experimental k_mac_synthesis (AL_FUSED=1)."""
-    monkeypatch.setenv("AL_FUSED", "1")
+    set_switch(monkeypatch, "AL_FUSED", "1")
     mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True, expect_split=False)
 
 
@@ -227,26 +229,26 @@ def test_quad16_transforms_all_rows(gpu, monkeypatch):
     unchanged accumulate.  cfg5's regime (12 partitions in three runs of four, 12 blocks), a short batch with a ragged last
     partition and edge windows, a moving event (the rolled general signal path, sliding-window accumulate), every row against
     the oracle; then the separate IR / signal launches (al_ir_spectra + al_signal_spectra) against the merged one, bit for bit."""
-    monkeypatch.delenv("AL_QUAD16", raising=False)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(4 << 24))       # AL_FLAG_IR_RUN(4): three runs of four partitions (a batch this small gets runs of one)
+    set_switch(monkeypatch, "AL_QUAD16", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(4 << 24))       # AL_FLAG_IR_RUN(4): three runs of four partitions (a batch this small gets runs of one)
     res = mr.run_static_case(gpu, 14, 3121201, 192000 / 16384, 192000 / 16384, C=3, E=2, expect_split=True, expect_quad=True)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(12 << 24))      # one run of twelve, as the full-size cfg5 batch runs
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(12 << 24))      # one run of twelve, as the full-size cfg5 batch runs
     mr.run_static_case(gpu, 14, 3121201, 192000 / 16384, 192000 / 16384, C=2, E=1, expect_split=True, expect_quad=True)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(5 << 24))       # unequal runs: 5 + 2
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(5 << 24))       # unequal runs: 5 + 2
     mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)
-    monkeypatch.delenv("AL_EXTRA_FLAGS")
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 12
     mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=True, expect_quad=True)
     mr.run_static_case(gpu, 14, 3120701, 3.2, 6.01, C=2, E=1, expect_split=True, expect_quad=True)
     mr.run_moving_case(gpu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
     mr.run_separate_forward_launches(gpu, 14)
-    monkeypatch.setenv("AL_QUAD16", "0")       # and the one-transform kernels of round 1 still serve B = 16384
+    set_switch(monkeypatch, "AL_QUAD16", "0")       # and the one-transform kernels of round 1 still serve B = 16384
     mr.run_static_case(gpu, 14, 3120301, 6.5, 2.5, C=3, E=2, expect_split=False, expect_quad=False)
 
 
 def test_quad16_random_batches(gpu, monkeypatch):
     """Seeded random batches (static / moving / zero-emitter events mixed) at B = 16384 through the quad-tile transforms."""
-    monkeypatch.delenv("AL_QUAD16", raising=False)
+    set_switch(monkeypatch, "AL_QUAD16", None)
     for seed in (3, 11, 29):
         mr.run_random_batch(gpu, seed, log2_block=14)
 
@@ -256,7 +258,7 @@ def test_random_shapes_over_the_whole_dispatch_space(gpu, monkeypatch, seed):
     """Seeded random batches: 1..26 partitions x clips of up to 60 blocks x static / moving / zero-emitter events mixed in one
     batch (B = 1024 for two thirds of the seeds, 8192 for the rest), every row against the oracle: the accumulate kernels
     beside each other as real scenes mix them, not one regime per batch."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
-    monkeypatch.delenv("AL_FUSED", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
+    set_switch(monkeypatch, "AL_FUSED", None)
     mr.run_random_batch(gpu, seed, log2_block=13 if seed % 3 == 2 else 10)

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from oracle import synth_oracle as orc
-from tests.conftest import assert_parity, rel_rms
+from tests.conftest import assert_parity, rel_rms, set_switch
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -215,9 +215,9 @@ def test_random_batches_vs_oracle(gpu, planning, seed, monkeypatch):
     rng = np.random.default_rng(1000 + seed)
     log2_block = int(rng.integers(10, 15))
     if seed % 3 == 1:
-        monkeypatch.setenv("AL_EXTRA_FLAGS", str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)))
+        set_switch(monkeypatch, "AL_EXTRA_FLAGS", str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)))
     elif seed % 3 == 2:
-        monkeypatch.setenv("AL_EXTRA_FLAGS", "4")
+        set_switch(monkeypatch, "AL_EXTRA_FLAGS", "4")
     sr, C = 16000, int(rng.integers(1, 8))
     L = int(rng.integers(1, 3 << log2_block))
     specs, clips, irs, col = [], [], [], 0

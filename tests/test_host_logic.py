@@ -21,7 +21,7 @@ def test_cabi_library_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "audiblelight_hip.h")).read()
     declared = set(re.findall(r"\b(al_[a-z0-9_]+)\s*\(", header))
     assert declared == set(_hip.SYMBOLS), declared ^ set(_hip.SYMBOLS)
-    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 5
+    assert lib.call("al_abi_version") == _hip.ABI_VERSION == 6
     assert lib.call("al_twiddle_bytes", 13) == 8 * 8192 and lib.call("al_twiddle_bytes", 9) == -1
     assert lib.call("al_row_stats_partials", 3, 40000) == 4 * 3 * 3
     assert lib.call("al_noise_workspace_floats", 2, 1000) > 0
@@ -47,7 +47,7 @@ def test_struct_layouts_match_the_header():
     assert ct.sizeof(_hip.AlBatch) == 2 * 4 + 6 * 4 + 2 * 8 + 4 * 4 + 6 * 4 + 16 * 8 + 2 * 4 + 8   # head, ..., 16 pointers, the two zero-block indices, emitter_parts
     assert ct.sizeof(_hip.AlMix) == 2 * 4 + 6 * 4 + 13 * 8
     b, m = _hip.AlBatch(log2_block=13), _hip.AlMix()
-    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (232, 5, 136, 5)
+    assert (b.struct_size, b.abi_version, m.struct_size, m.abi_version) == (232, 6, 136, 6)
     assert _hip.AlBatch.twiddle.offset % 8 == 0 and _hip.EVENT_DTYPE.fields["snr"][1] == 44
 
 
@@ -186,6 +186,42 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     # a launcher that sets WORLD_SIZE differently from --gpus is an error, not a silent 1-GPU run
     bad = subprocess.run(cmd, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"), capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and "--gpus 2 but WORLD_SIZE=1" in bad.stderr
+
+
+def test_bench_line_carries_parity_of_what_it_timed():
+    """The single-rank bench line compares the scene buffer its timed steps wrote with the oracle's mix of ALL events (the
+    scene the cpu_baseline leg renders anyway): `parity` = both halves of the 1e-4 contract over every capsule row and sample,
+    exit code 1 above tolerance; a bounded `--parity-events` goes through a GPU mixdown of those events alone.  Host-emulated
+    kernels here (the arithmetic is the same C++ code compiled for the CPU), the gfx950 build on the GPU box.  A non-default
+    A/B switch shows up in config.switches."""
+    import json
+    import subprocess
+    import sys
+
+    from tests import hostemu
+
+    hostemu.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK") and not k.startswith("AL_")}
+    env.update(AL_BENCH_EMULATE="1")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--repeats", "1", "--config", "cfg2",
+           "--scale", "0.02", "--cpu-workers", "0", "--end-to-end", "0", "--dropin", "0"]
+
+    def run(extra, **more_env):
+        res = subprocess.run(cmd + extra, env=dict(env, **more_env), capture_output=True, text=True, timeout=900)
+        assert res.returncode == 0, res.stderr[-2000:]
+        return json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+
+    out = run(["--cpu-events", "64"])
+    par = out["parity"]
+    assert par["ok"] and par["events"] == 64 and par["rows"] == 32 and par["samples"] == round(60 * 0.02 * 48000)
+    assert 0 < par["rel_rms"] < 1e-5 and 0 < par["max_abs_over_peak"] < 1e-5 and par["tol"] == 1e-4
+    assert "timed steps wrote" in par["note"] and out["config"]["switches"] == {}
+    assert out["cpu_baseline"]["extrapolated"] is False
+    out = run(["--cpu-events", "2", "--parity-events", "5"], AL_STATIC_MAC="0")
+    assert out["parity"]["ok"] and out["parity"]["events"] == 5 and "first 5 of 64" in out["parity"]["note"]
+    assert out["config"]["switches"] == {"static_mac": False}
+    assert "parity" not in run(["--cpu-events", "0", "--parity-events", "0"])
 
 
 def test_bench_eight_ranks_scene_batch_index_arithmetic():
@@ -522,3 +558,60 @@ def test_c_planner_edge_cases():
     mix = planning.plan_mixdown([0.99999, 0.5], [1.5, 0.50001], [4000, 10], [2, 2], [0, 8000], [0, 1], 1.0, 8000, 2)
     assert mix.skipped == [0, 1] and list(mix.tile_ptr) == [0, 0, 0]   # both slots are empty after rounding (synthesize.py:364-370)
     assert lib.call("al_choose_log2_block", 96000, 192000) == 13 and lib.call("al_stft_frame_count", 9000, 128) == 73
+
+
+def test_dispatch_policy_lives_behind_the_c_abi():
+    """al_plan_batch_flags (csrc/al_plan.cpp) against an independent statement of the rule -- split layout at B = 8192, + quad
+    tiles at 16384, capsule-loop accumulate for one-emitter events up to 21 partitions, ONLY_STATIC for chunks without a
+    multi-emitter event -- on random plans and chunkings; and the descriptors engine.Renderer.prepare builds carry exactly those
+    flags (no policy left in Python: switches.current() is all-default here)."""
+    from audiblelight_amd import engine, plan as planning, switches
+    from tests import hostemu
+
+    assert switches.current().non_default() == {} and not switches.current().forces_dispatch
+    lib = _hip.Library(hostemu.build())
+    r = engine.Renderer(lib=lib, memory=hostemu.NumpyMemory())
+    rng = np.random.default_rng(11)
+    seen = set()
+    for trial in range(60):
+        lb = int(rng.choice([10, 11, 12, 13, 14]))
+        B = 1 << lb
+        n_ev = int(rng.integers(1, 6))
+        P = int(rng.choice([1, 3, 12, 13, 21, 22, 25])) if lb <= 11 else int(rng.integers(1, 4))
+        ir_len = P * B - int(rng.integers(0, B // 2))
+        specs, col = [], 0
+        for _ in range(n_ev):
+            ne = int(rng.choice([0, 1, 1, 1, 3]))
+            n = int(rng.integers(B // 2, 3 * B))
+            specs.append(planning.EventSpec(n_samples=n, n_emitters=ne, snr=10.0, emitter0=col, is_moving=ne > 1, duration=n / 48000.0 if ne > 1 else None))
+            col += ne
+        if col == 0:
+            continue
+        pl = planning.plan_batch(specs, 2, ir_len, 48000.0, log2_block=lb, lib=lib)
+        step = int(rng.integers(1, n_ev + 1))
+
+        def want(chunk):
+            ev = pl.events[chunk["event0"]: chunk["event0"] + chunk["n_events"]]
+            f = {13: _hip.FLAG_SPLIT_SPECTRA, 14: _hip.FLAG_SPLIT_SPECTRA | _hip.FLAG_QUAD_SPECTRA}.get(lb, 0)
+            if pl.n_partitions <= 21 and (ev["n_streams"] == 1).any():
+                f |= _hip.FLAG_STATIC_MAC | (0 if (ev["n_streams"] > 1).any() else _hip.FLAG_ONLY_STATIC)
+            return f
+
+        chunks = pl.chunks(step)
+        for ch in chunks:
+            assert pl.batch_flags(ch) == want(ch), (trial, ch)
+            seen.add(want(ch))
+        whole = dict(event0=0, n_events=n_ev)
+        assert pl.batch_flags(None) == want(whole)
+        if lb <= 11 and trial % 4 == 0:      # the descriptors of a prepared batch (host emulation: small blocks only)
+            clips = [rng.standard_normal(sp.n_samples).astype(np.float32) for sp in specs]
+            irs = rng.standard_normal((2, col, ir_len)).astype(np.float32)
+            batch = r.prepare(pl, clips, irs, chunk_events=step)
+            for desc, ch in zip(batch.descs, chunks):
+                assert desc.flags == want(ch)
+    assert len(seen) >= 5, seen
+    with pytest.raises(_hip.HipError):
+        ch = _hip.AlChunk(event0=3, n_events=99)
+        import ctypes as ct
+
+        lib.call("al_plan_batch_flags", pl._c_plan(), ct.byref(ch), ct.byref(ct.c_int32()))

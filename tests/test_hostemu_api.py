@@ -9,7 +9,7 @@ import pytest
 from audiblelight_amd import _hip, augmentation as aug, core, engine, synthesize as syn
 from oracle import synth_oracle as orc
 from tests import hostemu
-from tests.conftest import assert_parity, pcm16, rel_rms
+from tests.conftest import assert_parity, pcm16, rel_rms, set_switch
 
 TOL = 1e-4
 
@@ -597,11 +597,11 @@ def test_big_batches_chunk_themselves(monkeypatch):
     irs = (rng.standard_normal((C, len(clips), L)) * np.exp(-np.arange(L) / 400.0)).astype(np.float32)
     specs = [planning.EventSpec(n_samples=len(c), n_emitters=1, snr=12.0, emitter0=i) for i, c in enumerate(clips)]
     pl = planning.plan_batch(specs, C, L, sr, log2_block=10)
-    monkeypatch.delenv("AL_WORKSPACE_GB", raising=False)
+    set_switch(monkeypatch, "AL_WORKSPACE_GB", None)
     whole = r.prepare(pl, clips, irs)
     assert len(whole.descs) == 1
     want = [whole.run().spatial_audio(i).copy() for i in range(len(clips))]
-    monkeypatch.setenv("AL_WORKSPACE_GB", str(pl.workspace_bytes() / 2.5 / 1e9))
+    set_switch(monkeypatch, "AL_WORKSPACE_GB", str(pl.workspace_bytes() / 2.5 / 1e9))
     assert r.auto_chunk_events(pl) == 2
     chunked = r.prepare(pl, clips, irs)
     assert len(chunked.descs) == 3 and [d.n_events for d in chunked.descs] == [2, 2, 2]

@@ -11,7 +11,7 @@ import pytest
 from audiblelight_amd import _hip, engine, plan as planning
 from oracle import synth_oracle as orc
 from tests import hostemu
-from tests.conftest import assert_parity, rel_rms
+from tests.conftest import assert_parity, rel_rms, set_switch
 
 TOL = 1e-4  # BASELINE.json north_star: outputs within 1e-4 relative RMS of the float64 reference
 
@@ -46,7 +46,7 @@ def test_emu_static_event_matches_reference(emu, golden, log2_block):
 @pytest.mark.parametrize("log2_block", [13, 14])
 def test_emu_narrow_transforms_at_large_blocks(emu, golden, monkeypatch, log2_block):
     """B >= 8192 defaults to 32 complex values per thread; AL_FLAG_NARROW_FFT keeps the 16-value kernels reachable."""
-    monkeypatch.setenv("AL_EXTRA_FLAGS", "4")   # AL_FLAG_NARROW_FFT
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", "4")   # AL_FLAG_NARROW_FFT
     a, h = golden["g1b_audio"], golden["g1b_irs"]
     pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=0.5, ref_db=-50)],
                              n_capsules=3, ir_len=h.shape[2], sample_rate=8000, log2_block=log2_block)
@@ -56,7 +56,7 @@ def test_emu_narrow_transforms_at_large_blocks(emu, golden, monkeypatch, log2_bl
 @pytest.mark.parametrize("log2_block", [10, 13])
 def test_emu_runs_of_blocks_per_workgroup(emu, golden, monkeypatch, log2_block):
     """AL_FLAG_SYNTH_RUN / AL_FLAG_IR_RUN: several output blocks / IR partitions per workgroup (loop + prefetch)."""
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str((3 << 16) | (2 << 24)))
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str((3 << 16) | (2 << 24)))
     a, h = golden["g1_audio"], golden["g1_irs"]
     pl = planning.plan_batch([planning.EventSpec(n_samples=len(a), n_emitters=1, snr=10.0)], 4, h.shape[2], 8000,
                              log2_block=log2_block)

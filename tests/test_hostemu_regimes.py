@@ -3,6 +3,8 @@ p-tile loops, KSPLIT workgroup mapping and the sliding-window kernel, every row 
 build repeats these at every block size in tests/test_gpu_mac_regimes.py."""
 import pytest
 
+from tests.conftest import set_switch
+
 from audiblelight_amd import _hip, engine
 from tests import hostemu, mac_regimes as mr
 
@@ -14,7 +16,7 @@ def emu():
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
 def test_emu_static_regimes(emu, name, code, k_mult, p_mult, monkeypatch):
-    monkeypatch.setenv("AL_STATIC_MAC", "0")   # the tile kernels
+    set_switch(monkeypatch, "AL_STATIC_MAC", "0")   # the tile kernels
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=2)
 
 
@@ -23,7 +25,7 @@ def test_emu_static_regimes(emu, name, code, k_mult, p_mult, monkeypatch):
 def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeypatch):
     """k_spectral_mac_static under emulation: paired k-tiles with a half-empty second tile and masked partitions, the
     6-partition instantiations, the capsule-range split."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=C, E=E)
 
 
@@ -31,28 +33,28 @@ def test_emu_static_capsule_loop_kernel(emu, code, k_mult, p_mult, C, E, monkeyp
 def test_emu_every_capsule_loop_instantiation(emu, monkeypatch, name, code, k_mult, p_mult, C, E):
     """The case table the GPU suite runs at B = 8192 and 1024 (partition counts 1..21 x three clip-length regimes + edges), here
     at B = 1024 on the host-emulated kernels: the index arithmetic of every capsule-loop instantiation is checked on CPU too."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
     mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1)
 
 
 @pytest.mark.parametrize("name,code,k_mult,p_mult,C,E", mr.GLDS_CASES[::3] + mr.NO_ZERO_BLOCK_CASES[::3],
                          ids=[c[0] for c in mr.GLDS_CASES[::3] + mr.NO_ZERO_BLOCK_CASES[::3]])
 def test_emu_glds_switch_and_no_zero_block(emu, monkeypatch, name, code, k_mult, p_mult, C, E):
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
     if code % 10 == 4:
-        monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+        set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(1 << 14))
         mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1)
     else:
-        monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+        set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
         mr.run_static_case(emu, 10, code, k_mult, p_mult, C=min(C, 2), E=1, zero_block=False)
 
 
 def test_emu_static_glds_kernel(emu, monkeypatch):
     """k_spectral_mac_static_glds under emulation (the LDS-DMA pieces as plain copies: ring indexing, piece -> row mapping,
     the repeated last piece where PT * 4 is not a multiple of 8, ragged second k-tile)."""
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(1 << 14))
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(1 << 14))
     mr.run_static_case(emu, 10, 3120904, 17.3, 8.6, C=3, E=1)
     mr.run_static_case(emu, 10, 3120304, 26.3, 2.5, C=2, E=1)
 
@@ -68,15 +70,15 @@ def test_emu_fused_moving_kernel(emu, monkeypatch, p_mult, n_irs, k_mult, expect
     """k_moving_fused (csrc/al_quad.h, B = 8192) under emulation: the fold of a partition into each quad tile, the four
     2048-point transforms per round, the real-FFT unpacking of tile 0, the LDS stage, passes over the partitions that add to
     stored blocks; the IR spectra workspace stays poisoned.  Every row against the oracle."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "1")
+    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
     mr.run_moving_case(emu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=2, E=1)
 
 
 def test_emu_quad_layout_alone(emu, monkeypatch):
     """The quad slot maps of the split kernels (QuadSlots, csrc/al_fft.h) without the fused kernel (AL_QUAD=1): static events
     through the capsule loop, moving ones through k_spectral_mac_moving over stored spectra in that layout."""
-    monkeypatch.setenv("AL_FUSED_MOVING", "0")
-    monkeypatch.setenv("AL_QUAD", "1")
+    set_switch(monkeypatch, "AL_FUSED_MOVING", "0")
+    set_switch(monkeypatch, "AL_QUAD", "1")
     mr.run_static_case(emu, 13, 3120301, 6.5, 2.5, C=2, E=1, expect_split=True, expect_quad=True)
 
 
@@ -85,22 +87,22 @@ def test_emu_quad16_transforms(emu, monkeypatch):
     (the prefetch hand-over between partitions), interior and edge signal windows, the rolled general signal path with cross-fade
     envelopes (moving event), the inverse that assembles a block from the four tiles; every row against the oracle.  And with
     AL_QUAD16=0 the one-transform kernels of round 1 still serve B = 16384."""
-    monkeypatch.delenv("AL_QUAD16", raising=False)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(3 << 24))       # AL_FLAG_IR_RUN(3): one run of three partitions per IR row (a batch this small gets runs of one)
+    set_switch(monkeypatch, "AL_QUAD16", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(3 << 24))       # AL_FLAG_IR_RUN(3): one run of three partitions per IR row (a batch this small gets runs of one)
     mr.run_static_case(emu, 14, 3120301, 3.5, 2.5, C=2, E=2, expect_split=True, expect_quad=True)
-    monkeypatch.setenv("AL_EXTRA_FLAGS", str(2 << 24))       # unequal runs: 2 + 1
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(2 << 24))       # unequal runs: 2 + 1
     mr.run_static_case(emu, 14, 3120301, 3.5, 2.5, C=1, E=1, expect_split=True, expect_quad=True)
-    monkeypatch.delenv("AL_EXTRA_FLAGS")
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
     mr.run_moving_case(emu, 14, 2.3, n_irs=6, k_mult=5.2, expect_moving=612, C=2, E=1)
     mr.run_separate_forward_launches(emu, 14)
-    monkeypatch.setenv("AL_QUAD16", "0")
+    set_switch(monkeypatch, "AL_QUAD16", "0")
     mr.run_static_case(emu, 14, 3120201, 2.2, 1.5, C=1, E=1, expect_split=False, expect_quad=False)
 
 
 def test_emu_fused_static_kernel(emu, monkeypatch):
     """k_mac_synthesis (B = 8192) under emulation: three k-tiles with a ragged last one, a partly empty partition tile,
     the bin-0 fix-up, the LDS hand-over into the transform layout; every row against the oracle."""
-    monkeypatch.setenv("AL_FUSED", "1")
+    set_switch(monkeypatch, "AL_FUSED", "1")
     mr.run_static_case(emu, 13, 1121202, 9.3, 5.002, C=1, E=1, expect_fused=True)
 
 
@@ -108,13 +110,13 @@ def test_emu_split_layout_transforms(emu, monkeypatch):
     """csrc/al_split.h under emulation (B = 2048, the smallest it is built for): even / odd half spectra, the LDS layout
     change of the difference signal, the combine of the two half-size inverses; static (two k-tiles, ragged partitions)
     and moving events, every row against the oracle."""
-    monkeypatch.setenv("AL_SPLIT", "1")
+    set_switch(monkeypatch, "AL_SPLIT", "1")
     mr.run_static_case(emu, 11, 3120601, 10.0006, 5.002, C=2, E=1, expect_split=True)
     mr.run_moving_case(emu, 11, 4.3, n_irs=10, k_mult=14.2, expect_moving=612, C=1, E=1)
 
 
 @pytest.mark.parametrize("seed", range(10))
 def test_emu_random_shapes_over_the_whole_dispatch_space(emu, monkeypatch, seed):
-    monkeypatch.delenv("AL_STATIC_MAC", raising=False)
-    monkeypatch.delenv("AL_EXTRA_FLAGS", raising=False)
+    set_switch(monkeypatch, "AL_STATIC_MAC", None)
+    set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
     mr.run_random_batch(emu, seed)

@@ -151,6 +151,7 @@ SYMBOLS = {
     "al_render_batch": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_mixdown": (ct.c_int, [ct.POINTER(AlMix), _S]),
     "al_scale_rows": (ct.c_int, [_P, ct.c_int64, _P, _S]),
+    "al_scale_rows_f64": (ct.c_int, [_P, ct.c_int64, _P, _S]),
     "al_clip_scales": (ct.c_int, [ct.POINTER(AlBatch), _P, _P, _S]),
     "al_peak_scale": (ct.c_int, [_P, ct.c_int64, ct.c_float, _P, _S]),
     "al_axpy": (ct.c_int, [_P, _P, _P, ct.c_int64, _S]),

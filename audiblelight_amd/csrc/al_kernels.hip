@@ -845,6 +845,11 @@ __global__ __launch_bounds__(256) void k_scale(float *x, int64_t n, const float 
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
 }
 
+__global__ __launch_bounds__(256) void k_scale_d(float *x, int64_t n, const double *scale) {
+  const float s = (float)*scale;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
+}
+
 __global__ __launch_bounds__(256) void k_axpy(float *y, const float *x, const float *a, int64_t n) {
   const float s = *a;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -1547,6 +1552,14 @@ int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream) {
   const int64_t blocks = (n + 255) / 256;
   hipLaunchKernelGGL(al::k_scale, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
   return check_launch("k_scale");
+}
+
+int al_scale_rows_f64(float *x, int64_t n, const double *scale, al_stream_t stream) {
+  if (!x || !scale || n < 0) return fail(AL_E_BADARG, "bad scale arguments");
+  if (n == 0) return AL_OK;
+  const int64_t blocks = (n + 255) / 256;
+  hipLaunchKernelGGL(al::k_scale_d, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, (hipStream_t)stream, x, n, scale);
+  return check_launch("k_scale_d");
 }
 
 int al_clip_scales(const al_batch *b, const float *prescale, const int32_t *mode, al_stream_t stream) {

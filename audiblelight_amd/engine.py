@@ -292,9 +292,25 @@ class RenderResult:
         flat = self.memory.download(self.spatial[int(ev["out_off"]): int(ev["out_off"]) + n])
         return flat.reshape(self.plan.n_capsules, int(ev["len"]))
 
+    def scaled_copy(self, lo: int, n: int, scale_ptrs: Sequence[int], f64_scale_ptrs: Sequence[int] = ()):
+        """A device copy of spatial[lo : lo + n] multiplied ON THE DEVICE by the float32 (``scale_ptrs``) and float64
+        (``f64_scale_ptrs``) scalars behind those device addresses (al_scale_rows / al_scale_rows_f64: the float32 product the
+        mixdown forms too): the host only copies and widens."""
+        piece = self.spatial[lo: lo + n]
+        tmp = piece.clone() if hasattr(piece, "clone") else np.array(piece)
+        for p in scale_ptrs:
+            self.lib.call("al_scale_rows", self.memory.ptr(tmp), n, p, self.memory.stream())
+        for p in f64_scale_ptrs:
+            self.lib.call("al_scale_rows_f64", self.memory.ptr(tmp), n, p, self.memory.stream())
+        return tmp
+
     def spatial_audio(self, i: int) -> np.ndarray:
-        """event.spatial_audio[mic]: the scaled (C, La) render (synthesize.py:599,606)."""
-        return self.raw_spatial(i).astype(np.float64) * self.scales()[i]
+        """event.spatial_audio[mic]: the scaled (C, La) render (synthesize.py:599,606), scaled by event_scale[i] on the device
+        and widened to float64 (the reference's dtype) after the copy."""
+        ev = self.plan.events[i]
+        n = self.plan.n_capsules * int(ev["len"])
+        dev = self.scaled_copy(int(ev["out_off"]), n, [self.memory.ptr(self.event_scale) + 4 * i])
+        return self.memory.download(dev)[:n].reshape(self.plan.n_capsules, int(ev["len"])).astype(np.float64)
 
 
 class Renderer:

@@ -74,26 +74,94 @@ def time_invariant_convolution(audio: np.ndarray, ir: np.ndarray) -> np.ndarray:
     return res.raw_spatial(0).astype(np.float64)
 
 
+def _envelope_geometry(fft_size: int, win_size: int, hop_size: int) -> bool:
+    """True where the envelope form of the STFT-domain algorithm holds: the sin^2 window at 50 % overlap
+    is a partition of unity and an fft_size-point frame holds the linear convolution of two win_size-sample frames."""
+    return win_size == 2 * hop_size and fft_size >= 2 * win_size - 1
+
+
+def _check_geometry(fft_size: int, win_size: int, hop_size: int) -> None:
+    """What the reference itself refuses (both ValueErrors there too): ``stft`` pads by win - hop on the left (np.pad raises for
+    a negative width, synthesize.py:124-127) and ``istft_overlap_synthesis`` adds fft_size-sample frames into a buffer of
+    (n_frames + 1) * hop + win samples (the last frame does not fit when fft_size > 2*hop + win: numpy's broadcast error,
+    synthesize.py:268-272)."""
+    if min(fft_size, win_size, hop_size) <= 0:
+        raise ValueError("fft_size, win_size and hop_size must be positive")
+    if win_size < hop_size:
+        raise ValueError(f"index can't contain negative values: win_size ({win_size}) must be at least hop_size ({hop_size})")
+    if fft_size > 2 * hop_size + win_size:
+        raise ValueError(f"operands could not be broadcast together: frames of fft_size = {fft_size} samples do not fit the "
+                         f"overlap-add buffer, fft_size must be at most 2*hop_size + win_size = {2 * hop_size + win_size}")
+
+
+def _permuted(buf, shape, axes):
+    """A contiguous device copy of ``buf`` viewed as ``shape`` with its axes permuted (a copy, no arithmetic)."""
+    n = int(np.prod(shape))
+    if hasattr(buf, "permute"):
+        return buf[:n].view(*shape).permute(*axes).contiguous().view(-1)
+    return np.ascontiguousarray(buf[:n].reshape(shape).transpose(axes)).reshape(-1)
+
+
+def _tv_chain_on_device(r, ir_dev, n_ch: int, n_irs: int, ir_pitch: int, audio_dev, n_audio: int, duration: float, sr: float,
+                        fft_size: int, win_size: int, hop_size: int):
+    """The reference's literal STFT-domain chain (synthesize.py:298-310) on device buffers, for STFT geometries outside the
+    envelope form: stft of the IRs and of the clip (al_stft), the frame-domain convolution with the cross-fade weights
+    (al_tv_stft_mac), inverse transforms + overlap-add (al_istft_ola).  ``ir_dev``: (C, N, ir_pitch) float32 rows (zero-padded
+    rows only add all-zero IR frames).  Returns (device (n_out, C) float32, n_out); nothing is synchronised or downloaded."""
+    mem, lib, st = r.mem, r.lib, r.mem.stream()
+    n_freq = fft_size // 2 + 1
+    f_ir = planning.stft_frame_count(ir_pitch, hop_size, lib=lib)
+    f_a = planning.stft_frame_count(n_audio, hop_size, lib=lib)
+    w = generate_interpolation_matrix(np.linspace(0, duration, n_irs), sr, hop_size, lib=lib)
+    n_frames = min(f_a, w.shape[0])
+    n_out = n_frames * hop_size - win_size
+    if n_frames <= 0 or n_out <= 0:
+        return mem.zeros(1), 0
+    rows = n_ch * n_irs
+    h_spec = mem.empty(2 * rows * f_ir * n_freq)
+    work = mem.empty(lib.call("al_stft_workspace_floats", rows * f_ir, fft_size))
+    lib.call("al_stft", mem.ptr(ir_dev), rows, ir_pitch, fft_size, win_size, hop_size, mem.ptr(h_spec), mem.ptr(work), st)
+    s_ir = _permuted(h_spec, (n_ch, n_irs, f_ir, n_freq, 2), (2, 3, 0, 1, 4))      # (F_ir, freq, C, N): the reference's layout
+    del h_spec
+    a_spec = mem.empty(2 * f_a * n_freq)
+    work = mem.empty(lib.call("al_stft_workspace_floats", f_a, fft_size))
+    lib.call("al_stft", mem.ptr(audio_dev), 1, n_audio, fft_size, win_size, hop_size, mem.ptr(a_spec), mem.ptr(work), st)
+    w_dev = mem.upload(np.ascontiguousarray(w, dtype=np.float32).reshape(-1))
+    y = mem.empty(2 * n_frames * n_freq * n_ch)
+    lib.call("al_tv_stft_mac", mem.ptr(a_spec), mem.ptr(s_ir), mem.ptr(w_dev), n_frames, f_ir, n_freq, n_ch, n_irs, mem.ptr(y), st)
+    out = mem.empty(n_out * n_ch)
+    work = mem.empty(lib.call("al_istft_workspace_floats", n_frames, n_ch, fft_size))
+    lib.call("al_istft_ola", mem.ptr(y), n_frames, n_freq, n_ch, fft_size, win_size, hop_size, mem.ptr(out), mem.ptr(work), st)
+    return out, n_out
+
+
 def time_variant_convolution(irs: np.ndarray, event, fft_size=config.FFT_SIZE, win_size=config.WIN_SIZE,
                              hop_size=config.HOP_SIZE) -> np.ndarray:
     """Time-variant convolution of a moving event: (C, N, L) IRs -> (C, n_frames*hop - win).
 
     Reference synthesize.py:277-310 (STFT-domain convolution with linear IR cross-fades).  Computed
-    here in the mathematically identical envelope form ("Moving events").
+    here in the mathematically identical envelope form ("Moving events") where that form
+    holds (win == 2*hop, fft >= 2*win - 1: the defaults), else by the literal chain on the device.
     """
     audio = np.asarray(event.load_audio(), dtype=np.float32)
     fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
-    if min(fft_size, win_size, hop_size) <= 0:
-        raise ValueError("fft_size, win_size and hop_size must be positive")
+    _check_geometry(fft_size, win_size, hop_size)
     n_ch, n_irs, n_ir = irs.shape
+    if not _envelope_geometry(fft_size, win_size, hop_size):
+        r = get_renderer()
+        ir_dev = r.mem.upload(np.ascontiguousarray(irs, dtype=np.float32).reshape(-1))
+        out, n_out = _tv_chain_on_device(r, ir_dev, n_ch, n_irs, n_ir, r.mem.upload(np.ascontiguousarray(audio)), len(audio),
+                                         float(event.duration), float(event.sample_rate), fft_size, win_size, hop_size)
+        return np.ascontiguousarray(r.mem.download(out)[: n_out * n_ch].reshape(n_out, n_ch).T).astype(np.float64)
     # the reference returns n_frames*hop - win samples, up to `hop` more than the clip: render into a
     # clip extended by win zeros while counting STFT frames on the original length
     clip = np.zeros(len(audio) + win_size, dtype=np.float32)
     clip[: len(audio)] = audio
     spec = planning.EventSpec(n_samples=len(clip), n_emitters=n_irs, snr=1.0, is_moving=True,
                               duration=event.duration, stft_len=len(audio))
-    pl = planning.plan_batch([spec], n_ch, n_ir, event.sample_rate, hop=hop_size, win=win_size, fft_size=fft_size)
-    res = get_renderer().render(pl, [clip], irs, normalize_irs=False)
+    r = get_renderer()
+    pl = planning.plan_batch([spec], n_ch, n_ir, event.sample_rate, hop=hop_size, win=win_size, fft_size=fft_size, lib=r.lib)
+    res = r.render(pl, [clip], irs, normalize_irs=False)
     return res.raw_spatial(0)[:, : int(pl.events["valid_len"][0])].astype(np.float64)
 
 
@@ -308,11 +376,62 @@ def _dry_batch(r: engine.Renderer, items, mic_alias: str, res: engine.RenderResu
     dry_res = dry.run(("al_forward_spectra", "al_emitter_gains", "al_spectral_mac", "al_block_synthesis"))
     for j, (event, _, _, index, em0) in enumerate(todo):
         def fetch(j=j, index=index, em0=em0):
-            gain = float(res.memory.download(res.emitter_gain)[em0])
-            return dry_res.raw_spatial(j)[0].astype(np.float64) * (gain * float(res.stats()[index, 3]))
+            # scaled on the device by the two results of the MAIN render it depends on -- emitter_gain[em0] (normalize_irs) and
+            # event_stats[index][3], the noise-floor multiplier the reference calls event_scale (synthesize.py:598,608) --
+            # and widened to float64 after the copy
+            ev = dry_res.plan.events[j]
+            mem = res.memory
+            dev = dry_res.scaled_copy(int(ev["out_off"]), int(ev["len"]), [mem.ptr(res.emitter_gain) + 4 * em0],
+                                      [mem.ptr(res.event_stats) + 8 * (4 * index + 3)])
+            return mem.download(dev)[: int(ev["len"])].astype(np.float64)
 
         event._spatial_audio_dry = as_lazy(getattr(event, "_spatial_audio_dry", None))
         LazyAudioDict.__setitem__(event._spatial_audio_dry, mic_alias, fetch)
+
+
+def _render_moving_general(r: engine.Renderer, spec, clip, irs: np.ndarray, fft_size: int, win_size: int, hop_size: int,
+                           sample_rate: float) -> engine.RenderResult:
+    """One moving event whose STFT geometry is outside the envelope form (win != 2*hop or fft < 2*win - 1), all on the device:
+    the batch machinery gives the buffers, the IR energies and normalize_irs' scalar per emitter (al_forward_spectra +
+    al_emitter_gains on a plan of this event; A1), the IR rows are scaled by those gains, the literal STFT chain convolves
+    (``_tv_chain_on_device``), the result lands truncated / zero-padded to the clip length in the batch's ``spatial`` buffer (A3),
+    al_row_stats + al_event_levels_from_stats evaluate the level law (A4/A5/A9).  The RenderResult is the one every other
+    event gets, so the lazy download, the dry render and the mixdown see no difference."""
+    import ctypes as ct
+
+    mem, lib, st = r.mem, r.lib, r.mem.stream()
+    n_ch, n_irs, n_ir = irs.shape
+    host_clip = engine.as_clip_source(clip)
+    pl = planning.plan_batch([spec], n_ch, n_ir, sample_rate, lib=lib)          # layout + tables only (default geometry)
+    batch = r.prepare(pl, [clip], irs)
+    desc = batch.descs[0]
+    for name in ("al_forward_spectra", "al_emitter_gains"):
+        lib.call(name, ct.byref(desc), st)
+    bufs = batch.bufs
+    pitch = int(desc.ir_stride_n)
+    gains = mem.ptr(bufs["emitter_gain"])
+    for c in range(n_ch):      # h[c, n, :] *= g[n]: one launch per capsule over its (N, pitch) rows
+        lib.call("al_scale_matrix_rows", mem.ptr(bufs["ir"]) + 4 * c * int(desc.ir_stride_c), n_irs, pitch, gains, st)
+    n_audio = len(host_clip)
+    audio_dev = bufs["audio"]      # the clip as uploaded (a finished clip: event.load_audio()'s peak-normalised array)
+    if bufs.get("clip_scale") is not None:   # folded scalar FX / device-side peak normalisation: applied to a copy of the clip
+        audio_dev = audio_dev[:n_audio].clone() if hasattr(audio_dev, "clone") else np.array(audio_dev[:n_audio])
+        lib.call("al_scale_rows", mem.ptr(audio_dev), n_audio, mem.ptr(bufs["clip_scale"]), st)
+    out, n_out = _tv_chain_on_device(r, bufs["ir"], n_ch, n_irs, pitch, audio_dev, n_audio, float(spec.duration), sample_rate,
+                                     fft_size, win_size, hop_size)
+    # (n_out, C) -> the event's (C, La) block of `spatial`, cut or zero-padded to the clip length (synthesize.py:590)
+    lo, keep = int(pl.events["out_off"][0]), min(n_out, n_audio)
+    block = bufs["spatial"][lo: lo + n_ch * n_audio]
+    block[:] = 0
+    if keep > 0:
+        if hasattr(block, "permute"):      # torch (HBM); else numpy (host emulation)
+            block.view(n_ch, n_audio)[:, :keep] = out[: n_out * n_ch].view(n_out, n_ch)[:keep].t()
+        else:
+            block.reshape(n_ch, n_audio)[:, :keep] = out[: n_out * n_ch].reshape(n_out, n_ch)[:keep].T
+    partials = mem.empty(lib.call("al_row_stats_partials", 1, n_ch * n_audio))
+    lib.call("al_row_stats", mem.ptr(block), 1, n_ch * n_audio, mem.ptr(partials), mem.ptr(bufs["event_stats"]), st)
+    lib.call("al_event_levels_from_stats", ct.byref(desc), n_ch, st)
+    return batch.result()
 
 
 def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEFAULT_REF_DB,
@@ -327,12 +446,18 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
     if mic_alias in getattr(event, "spatial_audio", {}).keys() and not ignore_cache:
         return
     n_ch, n_emitters, n_ir = irs.shape
+    fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
     clip = _clip_of(event, bool(ignore_cache))
     spec = _spec_of(event, clip, n_emitters, 0, ref_db)
-    pl = planning.plan_batch([spec], n_ch, max(n_ir, 1), event.sample_rate, hop=int(hop_size), win=int(win_size),
-                             fft_size=int(fft_size))
     r = get_renderer()
-    res = r.render(pl, [clip], irs)
+    if n_emitters > 1:
+        _check_geometry(fft_size, win_size, hop_size)
+    if n_emitters > 1 and not _envelope_geometry(fft_size, win_size, hop_size):
+        res = _render_moving_general(r, spec, clip, irs, fft_size, win_size, hop_size, float(event.sample_rate))
+    else:
+        geometry = dict(hop=hop_size, win=win_size, fft_size=fft_size) if n_emitters > 1 else {}   # static / tiled events never frame
+        pl = planning.plan_batch([spec], n_ch, max(n_ir, 1), event.sample_rate, lib=r.lib, **geometry)
+        res = r.render(pl, [clip], irs)
     res.check_finite()
     _publish(event, mic_alias, res, 0)
     _dry_batch(r, [(event, irs, 0, 0)], mic_alias, res)

@@ -250,6 +250,10 @@ int al_mixdown(const al_mix *m, al_stream_t stream);
 /* x[r, :] *= scale[r_index] for a (rows, cols) block: scales an event's spatial audio in place
  * (event.spatial_audio, synthesize.py:599,606). scale is a device pointer to ONE float. */
 int al_scale_rows(float *x, int64_t n, const float *scale, al_stream_t stream);
+/* The same with the scalar read from a DOUBLE on the device (rounded to float32 once): al_batch.event_stats[4 e + 3], the
+ * noise-floor multiplier db_to_multiplier(ref_db + snr, mean|x|) alone, which scales the dry render (synthesize.py:598,608 ->
+ * :432-504) -- event_scale[e] also carries the apply_snr factor and is not the reference's `event_scale`. */
+int al_scale_rows_f64(float *x, int64_t n, const double *scale, al_stream_t stream);
 /* A13 on the device, without a host round trip.  al_clip_scales: for every event of the batch, clip_scale[e] =
  * prescale[e] (mode[e] == 0) or prescale[e] / (|prescale[e]| * max|clip_e| + tiny(float32)) (mode[e] == 1): the
  * peak normalisation `a / max(|a| + tiny)` of event.py:535-536 applied to the clip prescale[e] * clip_e, i.e. behind a

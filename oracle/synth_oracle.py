@@ -230,8 +230,10 @@ def dry_path(audio: np.ndarray, irs_norm_cnl: np.ndarray, event_scale: float,
 def render_event(audio: np.ndarray, irs_cnl: np.ndarray, snr: float, ref_db: float = DEFAULT_REF_DB,
                  is_moving: bool = False, duration: Optional[float] = None, sr: float = 44100,
                  ref_ir_channel: Optional[int] = None, direct_path_time_ms=None,
-                 moving_impl: str = "envelope") -> dict:
-    """One event at one microphone (synthesize.py:507-608). audio is the loaded, peak-normalised clip."""
+                 moving_impl: str = "envelope", nfft=FFT_SIZE, win=WIN_SIZE, hop=HOP_SIZE) -> dict:
+    """One event at one microphone (synthesize.py:507-608). audio is the loaded, peak-normalised clip.
+    nfft / win / hop: the STFT geometry of a moving event (synthesize.py:514-516); the envelope form only holds for
+    win == 2*hop and nfft >= 2*win - 1, any other geometry goes through the literal STFT-domain restatement."""
     check_audio(audio)
     n_ch, n_emit, _ = irs_cnl.shape
     n_audio = audio.shape[0]
@@ -245,8 +247,9 @@ def render_event(audio: np.ndarray, irs_cnl: np.ndarray, snr: float, ref_db: flo
     else:
         if not is_moving:
             raise ValueError("Expected a moving event!")
-        fn = convolve_moving if moving_impl == "envelope" else convolve_moving_stft
-        wet = fn(audio, irs_n, duration, sr)
+        envelope_ok = win == 2 * hop and nfft >= 2 * win - 1
+        fn = convolve_moving if (moving_impl == "envelope" and envelope_ok) else convolve_moving_stft
+        wet = fn(audio, irs_n, duration, sr, nfft, win, hop)
     wet = fit_length(wet, n_audio)
     out, event_scale = level_law(wet, snr, ref_db)
     check_audio(out)

@@ -217,6 +217,7 @@ def main():
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
     stft_vectors(syn)
+    geometry_vectors(syn)
 
 
 def stft_vectors(syn):
@@ -243,6 +244,40 @@ def stft_vectors(syn):
     path = os.path.join(HERE, "reference_stft_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
+
+
+def geometry_vectors(syn):
+    """G14: moving events rendered with OTHER STFT geometries than the defaults (synthesize.py:507-516 exposes fft_size /
+    win_size / hop_size and :277-310 honours any values the framing accepts): win != 2*hop, fft < 2*win - 1 (time-aliased
+    frames), 75 % overlap, and a scaled copy of the default geometry; plus the geometries the reference itself REFUSES
+    (istft_overlap_synthesis needs fft <= 2*hop + win: numpy raises a broadcast ValueError otherwise; stft needs win >= hop:
+    np.pad raises).  A file of its own with its own seed: the other golden files are untouched."""
+    rng = np.random.default_rng(20261004)
+    sr, n_ir, n_caps = 8000, 4, 3
+    a = make_clip(rng, 6000)
+    h = make_irs(rng, n_caps, n_ir, 1500)
+    out = dict(g14_audio=a, g14_irs=h.astype(np.float32))
+    geoms = [(512, 256, 192), (256, 256, 128), (384, 256, 64), (1024, 512, 256), (512, 384, 128), (300, 200, 100)]
+    out["g14_geometries"] = np.array(geoms)
+    for fft_size, win, hop in geoms:
+        ev = FakeEvent("g14", a, n_ir, snr=11.0, sr=sr, is_moving=True)
+        syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=fft_size, win_size=win, hop_size=hop)
+        hn = syn.normalize_irs(h.transpose(1, 0, 2)).transpose(1, 0, 2)
+        raw = syn.time_variant_convolution(hn, ev, fft_size, win, hop)
+        tag = f"g14_{fft_size}_{win}_{hop}"
+        out[tag + "_spatial"] = ev.spatial_audio["mic000"]
+        out[tag + "_raw"] = raw
+    refused = []
+    for fft_size, win, hop in [(1024, 512, 128), (512, 256, 64), (512, 128, 256)]:
+        ev = FakeEvent("g14", a, n_ir, snr=11.0, sr=sr, is_moving=True)
+        try:
+            syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=fft_size, win_size=win, hop_size=hop)
+        except ValueError:
+            refused.append((fft_size, win, hop))
+    out["g14_refused"] = np.array(refused)
+    path = os.path.join(HERE, "reference_geometry_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays; refused by the reference:", refused)
 
 
 if __name__ == "__main__":

@@ -371,6 +371,46 @@ def test_stft_helpers_match_reference():
         syn.stft(a, 2 * 11 * 13, 256, 128)
 
 
+def test_moving_events_under_other_stft_geometries():
+    """A7 with fft_size / win_size / hop_size other than the defaults (synthesize.py:507-516 exposes them, :277-310 honours
+    any geometry the framing accepts) against the reference's own renders (G14, tests/golden/make_golden.py::geometry_vectors):
+    render_event_audio (normalize_irs -> time-variant convolution -> truncation -> level law) and time_variant_convolution,
+    through the envelope form where it holds (the scaled default 1024/512/256) and through the device STFT chain elsewhere
+    (win != 2*hop, fft < 2*win - 1, 75 % overlap, non-power-of-two sizes); what the reference refuses raises ValueError here."""
+    import os
+
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_geometry_vectors.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    a, h = z["g14_audio"], z["g14_irs"]
+    r = syn.get_renderer()
+    for fft_size, win, hop in z["g14_geometries"].tolist():
+        tag = f"g14_{fft_size}_{win}_{hop}"
+        ev = core.Event("g14", a, 8000, snr=11.0, n_emitters=4, is_moving=True)
+        syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=fft_size, win_size=win, hop_size=hop)
+        got = ev.spatial_audio["mic000"]
+        assert got.dtype == np.float64 and got.shape == z[tag + "_spatial"].shape
+        assert_parity(got, z[tag + "_spatial"], TOL, what=tag)
+        hn = syn.normalize_irs(h.astype(np.float64).transpose(1, 0, 2)).transpose(1, 0, 2)
+        raw = syn.time_variant_convolution(hn, ev, fft_size, win, hop)
+        assert raw.shape == z[tag + "_raw"].shape
+        assert_parity(raw, z[tag + "_raw"], TOL, what=tag)
+    # the mixdown takes such an event like any other (same RenderResult): scaled render summed into a scene
+    ev = core.Event("g14", a, 8000, snr=11.0, n_emitters=4, is_moving=True, scene_start=0.1)
+    syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=512, win_size=256, hop_size=192)
+    assert ev.spatial_audio.is_resident("mic000")
+    for fft_size, win, hop in z["g14_refused"].tolist():
+        ev = core.Event("g14", a, 8000, snr=11.0, n_emitters=4, is_moving=True)
+        with pytest.raises(ValueError):
+            syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=fft_size, win_size=win, hop_size=hop)
+        with pytest.raises(ValueError):
+            syn.time_variant_convolution(h.astype(np.float64), ev, fft_size, win, hop)
+    # a static event ignores the geometry arguments entirely, as in the reference (it never frames anything)
+    ev = core.Event("s", a, 8000, snr=11.0)
+    syn.render_event_audio(ev, h[:, :1], "mic000", ref_db=-65, fft_size=1024, win_size=512, hop_size=128)
+    assert np.isfinite(ev.spatial_audio["mic000"]).all()
+    assert r is syn.get_renderer()
+
+
 def test_fx_chain_stays_on_device_and_scalars_fold():
     """BASELINE configs[4]'s "gain/polarity augmentations fused" through the PRODUCT classes: events built with
     ``augmentations=[Gain, Invert]`` render to what the oracle gives for peak_normalise(invert(gain(raw))) with no FX

@@ -217,3 +217,32 @@ def test_g11_reference_fx_vectors_pin_the_oracle():
         decisions = [random.random() < float(prob) for _ in range(rows)]
         got = orc.fx_wrap(lambda v: orc.fx_timewarp(v, sr, float(fps), decisions, modes[name]), x)
         np.testing.assert_array_equal(got, z[f"tw_{i}"], err_msg=str(case))
+
+
+GEOMETRY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_geometry_vectors.npz")
+
+
+def test_g14_other_stft_geometries():
+    """G14 (tests/golden/make_golden.py::geometry_vectors): the reference's render of one moving event under six STFT
+    geometries -- win != 2*hop, fft < 2*win - 1, 75 % overlap, a scaled default, win > fft/2 with hop = win/3, non-power-of-two
+    sizes -- reproduced by the oracle's literal STFT-domain restatement to 1e-10; where the envelope identity holds
+    (win == 2*hop, fft >= 2*win - 1: the scaled default) the envelope form agrees as well."""
+    with np.load(GEOMETRY) as z:
+        z = {k: z[k] for k in z.files}
+    a, h = z["g14_audio"], z["g14_irs"].astype(np.float64)
+    assert len(z["g14_geometries"]) == 6 and len(z["g14_refused"]) == 3
+    for fft_size, win, hop in z["g14_geometries"].tolist():
+        tag = f"g14_{fft_size}_{win}_{hop}"
+        got = orc.render_event(a, h, 11.0, ref_db=-65, is_moving=True, duration=len(a) / 8000, sr=8000, nfft=fft_size, win=win,
+                               hop=hop)["spatial"]
+        assert rel_rms(got, z[tag + "_spatial"]) < 1e-10, tag
+        raw = orc.convolve_moving_stft(a, orc.unit_energy_irs(h.transpose(1, 0, 2)).transpose(1, 0, 2), len(a) / 8000, 8000,
+                                       fft_size, win, hop)
+        assert raw.shape == z[tag + "_raw"].shape and rel_rms(raw, z[tag + "_raw"]) < 1e-10, tag
+        if win == 2 * hop and fft_size >= 2 * win - 1:
+            env = orc.render_event(a, h, 11.0, ref_db=-65, is_moving=True, duration=len(a) / 8000, sr=8000, nfft=fft_size,
+                                   win=win, hop=hop, moving_impl="envelope")["spatial"]
+            assert rel_rms(env, z[tag + "_spatial"]) < 1e-10
+    # what the reference refuses: frames longer than the overlap-add buffer allows (fft > 2*hop + win) and win < hop
+    for fft_size, win, hop in z["g14_refused"].tolist():
+        assert fft_size > 2 * hop + win or win < hop

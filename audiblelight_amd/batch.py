@@ -97,7 +97,7 @@ class BatchDriver:
         self.async_h2d = sw.h2d == "async"   # same rate measured (profiles/r02_e2e_probe.txt)
         # threads that cast float64 IR tensors to float32 in the planner stage (0: upload the float64 bytes, cast on the device)
         # 16: 17.2-19.1 ms per cfg2 scene against 19.5-27.8 with 8 and 16.0 for float32 IRs (profiles/r03i_f64_threads_ab.txt)
-        self.cast_threads = int(sw.convert_threads or 16) if sw.f64_upload == "host" else 0
+        self.cast_threads = engine.host_threads(sw.convert_threads or 16) if sw.f64_upload == "host" else 0
         self._cast_pool = None
 
     def _pinned_buffer(self, tag: str, dtype, numel: int, slot: int):

@@ -29,6 +29,60 @@ def shard_stream(items, rank: int, world_size: int):
             yield item
 
 
+def host_share(local_rank: int, local_world: int, device_index: Optional[int] = None, pin: bool = True) -> dict:
+    """This rank's share of the host: N ranks on one node must not each size their helper pools (IR cast threads, clip packers,
+    the batch driver's planner / uploader / writer) for the whole machine.  Returns {"cpus": usable CPUs of this rank,
+    "threads": the cap for any one pool, "numa_node", "pinned"}.  With ``pin`` the process is restricted (sched_setaffinity) to
+    the CPUs local to its GPU's NUMA node (sysfs ``local_cpulist`` of the GPU's PCI function) when the node can be found --
+    H2D staging and page-locked buffers then live next to the GPU -- else to an equal contiguous slice of the usable CPUs.
+    Best effort: any failure leaves the affinity alone and only the cap applies."""
+    import os
+
+    try:
+        usable = sorted(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        usable = list(range(os.cpu_count() or 1))
+    local_world = max(int(local_world), 1)
+    out = {"cpus": len(usable), "threads": max(1, len(usable) // local_world), "numa_node": None, "pinned": False}
+    mine: List[int] = []
+    if device_index is not None:
+        try:
+            import torch
+
+            pr = torch.cuda.get_device_properties(device_index)
+            bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+            base = f"/sys/bus/pci/devices/{bdf}"
+            node = int(open(f"{base}/numa_node").read())
+            cpus = _parse_cpulist(open(f"{base}/local_cpulist").read())
+            mine = [c for c in cpus if c in set(usable)]
+            out["numa_node"] = node if node >= 0 else None
+        except Exception:  # noqa: BLE001 -- no sysfs entry, no such attribute: fall through to the equal slice
+            mine = []
+    if mine:
+        # several GPUs usually share one NUMA node: the ranks of that node split its CPUs between them
+        out["threads"] = max(1, min(out["threads"], len(mine)))
+    else:
+        per = max(1, len(usable) // local_world)
+        mine = usable[(local_rank % local_world) * per: (local_rank % local_world) * per + per] or usable
+    if pin and local_world > 1:
+        try:
+            os.sched_setaffinity(0, mine)
+            out["pinned"], out["cpus"] = True, len(mine)
+        except (AttributeError, OSError):
+            pass
+    return out
+
+
+def _parse_cpulist(text: str) -> List[int]:
+    cpus: List[int] = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus += list(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
 def init_process_group(backend: Optional[str] = None):
     """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
     import os
@@ -105,7 +159,8 @@ def gather_buffers(local: Dict[int, "object"], n_items: int, dst: int = 0, devic
     return {i: v.cpu().numpy() for i, v in out.items()}
 
 
-def render_and_gather_overlapped(render_fn: Callable[[int], "object"], n_items: int, shape, dst: int = 0, device=None):
+def render_and_gather_overlapped(render_fn: Callable[[int], "object"], n_items: int, shape, dst: int = 0, device=None,
+                                 producer_stream=None):
     """Render this rank's scenes and collect ALL ``n_items`` (C, T) float32 buffers on rank ``dst`` WHILE the rendering goes
     on: a scene is sent the moment its kernels are enqueued (the send is stream-ordered behind them), instead of all of them
     after the last one (``gather_buffers``).  All scenes have the same ``shape`` (BASELINE configs[3]: a batch of equal scenes).
@@ -113,7 +168,12 @@ def render_and_gather_overlapped(render_fn: Callable[[int], "object"], n_items: 
     The root posts its receives up front, one grouped launch per ROUND (round r = scenes r * world .. r * world + world - 1,
     one from every peer, each arriving over that peer's own xGMI link); a pair of ranks matches sends and receives in issue
     order, and every peer sends its scenes in ascending order.  ``render_fn(i)`` returns scene i's buffer on this rank's device
-    (a tensor that stays valid until this function returns).  Returns {index: tensor} on ``dst``, None elsewhere."""
+    (a tensor that stays valid until this function returns).  Returns {index: tensor} on ``dst``, None elsewhere.
+
+    Stream contract: RCCL orders a send behind the work ALREADY ENQUEUED ON TORCH'S CURRENT STREAM, nothing else.  Every render
+    path of this package enqueues there (TorchMemory.stream() is the current stream; multi-lane batches and graph replays join
+    back into it).  A ``render_fn`` that renders on a stream of its own passes it as ``producer_stream`` (a torch.cuda.Stream):
+    the current stream then waits for it before every send."""
     import torch
     import torch.distributed as dist
 
@@ -136,6 +196,8 @@ def render_and_gather_overlapped(render_fn: Callable[[int], "object"], n_items: 
                 reqs += dist.batch_isend_irecv(ops)
     for idx in shard_indices(n_items, rank, world):
         buf = render_fn(idx)
+        if producer_stream is not None and backend == "nccl":
+            torch.cuda.current_stream(dev).wait_stream(producer_stream)
         buf = (torch.from_numpy(np.ascontiguousarray(buf)) if isinstance(buf, np.ndarray) else buf).to(dev, dtype=torch.float32)
         if tuple(buf.shape) != (c, t):
             raise ValueError(f"scene {idx} has shape {tuple(buf.shape)}, the overlapped gather was set up for {(c, t)}")

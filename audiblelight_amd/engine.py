@@ -21,6 +21,21 @@ def _debug_flags() -> int:
     return switches.current().extra_flags & _hip.DEBUG_FLAG_MASK
 
 
+# ----------------------------------------------------------------------------- host thread budget
+_THREAD_CAP: Optional[int] = None
+
+
+def set_thread_cap(n: Optional[int]) -> None:
+    """Largest helper pool this process may start (IR cast threads, clip packers, the batch driver's cast pool): N ranks on one
+    node each take ``distributed.host_share(...)["threads"]`` instead of sizing their pools for the whole machine."""
+    global _THREAD_CAP
+    _THREAD_CAP = None if n is None else max(1, int(n))
+
+
+def host_threads(want: int) -> int:
+    return max(1, int(want)) if _THREAD_CAP is None else max(1, min(int(want), _THREAD_CAP))
+
+
 # ----------------------------------------------------------------------------- memory providers
 class TorchMemory:
     """HBM through torch (ROCm).  Raises if no GPU is visible: there is no CPU path."""
@@ -115,7 +130,7 @@ class TorchMemory:
 
         flat = np.ascontiguousarray(arr).reshape(-1)
         n = flat.size
-        threads = int(switches.current().convert_threads or threads or 8)
+        threads = host_threads(switches.current().convert_threads or threads or 8)
         if not hasattr(self, "_convert"):
             self._convert = dict(pool=None, threads=0, host=None, last=None)
         cv = self._convert
@@ -400,7 +415,7 @@ class Renderer:
         if _PACK_POOL is None:
             from concurrent.futures import ThreadPoolExecutor
 
-            _PACK_POOL = ThreadPoolExecutor(4)
+            _PACK_POOL = ThreadPoolExecutor(host_threads(4))
 
         def put(item):
             off, a = item

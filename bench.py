@@ -77,12 +77,61 @@ def under_profiler() -> bool:
             or "rocprofiler" in env.get("HSA_TOOLS_LIB", "").lower())
 
 
+def cpu_quota():
+    """What the container is ALLOWED to use, beside the CPUs it can see: cgroup v2 cpu.max ("max 100000" = no limit,
+    "<quota> <period>" = quota / period CPUs) or the v1 pair; plus the memory limit.  A quota below the visible CPU count turns
+    "one process per physical core" into time-slicing, which is the first thing to rule out when per-process times explode."""
+    out = {"cpu_max": None, "cpus_allowed_by_quota": None, "memory_max": None, "visible_cpus": os.cpu_count()}
+    try:
+        with open("/proc/self/cgroup") as fh:
+            rel = [ln.strip().split(":", 2)[2] for ln in fh if ln.startswith("0::")]
+        roots = ["/sys/fs/cgroup" + (rel[0] if rel else ""), "/sys/fs/cgroup"]
+    except OSError:
+        roots = ["/sys/fs/cgroup"]
+    for root in roots:
+        try:
+            raw = open(os.path.join(root, "cpu.max")).read().split()
+            out["cpu_max"] = " ".join(raw)
+            out["cpus_allowed_by_quota"] = None if raw[0] == "max" else float(raw[0]) / float(raw[1])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    if out["cpu_max"] is None:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p_ = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cpu_max"] = f"{q} {p_} (cgroup v1)"
+            out["cpus_allowed_by_quota"] = None if q < 0 else q / p_
+        except (OSError, ValueError):
+            pass
+    for root in roots:
+        try:
+            out["memory_max"] = open(os.path.join(root, "memory.max")).read().strip()
+            break
+        except OSError:
+            continue
+    return out
+
+
+def _pressure():
+    """/proc/pressure/{cpu,memory} "some avg10" (percent of time some task waited for the resource), None where PSI is off."""
+    out = {}
+    for res in ("cpu", "memory", "io"):
+        try:
+            line = open(f"/proc/pressure/{res}").readline()
+            out[res] = float(line.split("avg10=")[1].split()[0])
+        except (OSError, IndexError, ValueError):
+            out[res] = None
+    return out
+
+
 def _cpu_scene_worker(job):
     """ONE whole scene through the oracle in a worker process, the way the reference runs it (synthesize.py:613-677 then
     :314-401): every event rendered, added into the float32 scene buffer, and the reference's per-event full-scene padded copy
     (:381-383) built and dropped.  Input generation is outside the timing.  max_events / n_irs_cap bound the sample for the
     configurations whose full scene takes a core minutes or hours (cfg3, cfg5): then the time is scaled in events x IRs."""
-    config, index, scale, max_events, n_irs_cap = job
+    config, index, scale, max_events, n_irs_cap = job[:5]
+    keep_padded = job[5] if len(job) > 5 else True
     from audiblelight_amd import synthetic
     from oracle import synth_oracle as orc
 
@@ -104,15 +153,16 @@ def _cpu_scene_worker(job):
         if b > a:
             piece = orc.fit_length(x, b - a)
             scene[:, a:b] += piece
-            padded = np.zeros_like(scene)            # event._spatial_audio_padded[mic]
-            padded[:, a:b] += piece
-            del padded
+            if keep_padded:
+                padded = np.zeros_like(scene)            # event._spatial_audio_padded[mic]
+                padded[:, a:b] += piece
+                del padded
         work += max(n_used, 1)
     orc.check_audio(scene)
     return time.perf_counter() - t0, work
 
 
-def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, n_irs_cap=8, max_events=None):
+def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, n_irs_cap=8, max_events=None, keep_padded=True):
     """the oracle on every physical core of the host, ONE PROCESS PER SCENE (scenes are independent; the
     reference's dataset loop is serial, scripts/generate/benchmark.py:44-77): `workers` different scenes rendered at once,
     mixdown and per-event padded copies included.  rate = scenes x scene seconds / wall time of the slowest worker."""
@@ -129,7 +179,8 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
         max_events = {"cfg2": 6, "cfg3": 1, "cfg4": 6, "cfg5": 2}.get(config, 0)
     max_events = min(max_events, cfg["E"]) if max_events else 0
     duration = cfg["T"] * scale
-    jobs = [(config, 10_000 + i, scale, max_events, n_irs_cap) for i in range(workers)]
+    jobs = [(config, 10_000 + i, scale, max_events, n_irs_cap, keep_padded) for i in range(workers)]
+    before = _pressure()
     # spawn, not fork: a broken worker raises instead of hanging.  Started BEFORE this process initialises the GPU.
     with ProcessPoolExecutor(workers, mp_context=mp.get_context("spawn")) as pool:
         t0 = time.perf_counter()
@@ -140,7 +191,8 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
     extrapolated = sample_work < full_work
     per_scene_s = slowest * full_work / max(sample_work, 1)
     return dict(value=workers * duration / per_scene_s, unit="scene-seconds/s", cores=workers, host_cpus=os.cpu_count(), kind="port",
-                cpu_model=cpu_model(), core_count_from=how, extrapolated=extrapolated,
+                cpu_model=cpu_model(), core_count_from=how, extrapolated=extrapolated, cpu_quota=cpu_quota(),
+                pressure_avg10_before_after={"before": before, "after": _pressure()}, per_event_padded_copies=bool(keep_padded),
                 seconds_per_scene_per_core=[round(min(t for t, _ in results), 2), round(slowest, 2)],
                 wall_s_including_input_generation=round(wall_with_inputs, 1),
                 sample=f"{workers} different {config} scenes at once, one oracle process per scene on one physical core each: "
@@ -148,6 +200,48 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
                           f"{max_events} of {full_events} events" + (f" with {n_irs_cap} IRs each" if config == "cfg3" else "")
                           + ", scaled linearly in events x IRs (--cpu-scene-events 0 renders whole scenes: minutes)")
                        + " + float32 mixdown + the reference's per-event padded copies; rate from the slowest worker")
+
+
+def cpu_workers_sweep(args):
+    """The all-cores leg at several worker counts (one whole-scene oracle process per worker, `--cpu-scene-events` events each),
+    with and without the per-event full-scene padded copy of synthesize.py:381-383.  Reports the aggregate rate per point, the
+    per-worker seconds, the container's CPU quota and the knee: the first count whose aggregate rate gains less than half of
+    what a linear continuation from the previous point would."""
+    from audiblelight_amd import synthetic
+
+    cores, how = physical_cores()
+    cfg = synthetic.CONFIGS[args.config]
+    counts = [int(x) for x in args.cpu_workers_sweep.split(",") if x.strip()]
+    events = None if args.cpu_scene_events < 0 else (args.cpu_scene_events or cfg["E"])
+    points = []
+    # third variant, at the largest count only: glibc malloc asking for transparent huge pages (GLIBC_TUNABLES, inherited by the
+    # spawned workers) -- every event allocates and frees hundreds of MB of float64 temporaries, i.e. ~10^5 fresh 4 KiB page
+    # faults per event per process; if the per-process slowdown is the kernel's page allocator under 128 faulting processes,
+    # 2 MiB pages remove it
+    variants = [(True, False, counts), (False, False, counts), (True, True, counts[-1:])]
+    for padded, thp, which in variants:
+        for n in which:
+            saved = os.environ.get("GLIBC_TUNABLES")
+            if thp:
+                os.environ["GLIBC_TUNABLES"] = "glibc.malloc.hugetlb=1"
+            try:
+                rec = cpu_baseline_all_cores(args.config, args.scale, n, how, cfg["E"], cfg["E"] * cfg["N"], max_events=events,
+                                             keep_padded=padded)
+            finally:
+                if thp:
+                    os.environ.pop("GLIBC_TUNABLES", None) if saved is None else os.environ.__setitem__("GLIBC_TUNABLES", saved)
+            points.append({"workers": n, "padded_copies": padded, "malloc_huge_pages": thp, "scene_seconds_per_s": rec["value"],
+                           "seconds_per_scene_per_worker_min_max": rec["seconds_per_scene_per_core"], "wall_s": rec["wall_s_including_input_generation"],
+                           "pressure": rec["pressure_avg10_before_after"]["after"], "sample": rec["sample"]})
+    knee = None
+    with_pad = [p_ for p_ in points if p_["padded_copies"] and not p_["malloc_huge_pages"]]
+    for a, b in zip(with_pad, with_pad[1:]):
+        linear = a["scene_seconds_per_s"] * b["workers"] / a["workers"]
+        if b["scene_seconds_per_s"] - a["scene_seconds_per_s"] < 0.5 * (linear - a["scene_seconds_per_s"]):
+            knee = b["workers"]
+            break
+    return {"workers_sweep": points, "cpu_quota": cpu_quota(), "knee_workers": knee, "physical_cores": cores, "core_count_from": how,
+            "cpu_model": cpu_model(), "config": args.config, "scale": args.scale}
 
 
 def oracle_clip(scene, i):
@@ -241,6 +335,56 @@ def cpu_baseline(scene, n_events: int, n_irs_cap: int = 8, keep_scene: bool = Fa
     return (rec, None if capped else ref_scene) if keep_scene else rec
 
 
+VALU_PEAK_TFLOPS = 157.3   # MI355X vector fp32 (MI355X_MICROARCH.md "Chip-level parameters": 256 CUs x 4 SIMD-32 x 2 flop x 2.4 GHz)
+VALU_ISSUE_PER_S = 256 * 4 * 2.4e9 / 2.0   # wave64 VALU instructions the chip can issue per second: one per 2 cycles per SIMD-32
+                                           # with two or more waves on the SIMD (same guide, `v_fma_f32 (wave64): 2 cyc`)
+
+
+def stage_flops(pl, mix_plan):
+    """Floating-point operations one step performs per C-ABI stage, counted from the PLAN (not the monolithic-FFT convention of
+    SURVEY 8d's 107 GFLOP): a 2B-sample real transform = 2.5 N log2 N with N = 2B; one complex multiply-accumulate = 8 flops per
+    bin; the transforms / products of trimmed IR partitions (al_batch.emitter_parts) and of blocks past a clip's end are not
+    counted because they are not made."""
+    import math
+
+    B, C, P = pl.block, pl.n_capsules, pl.n_partitions
+    fft = 2.5 * (2 * B) * math.log2(2 * B)
+    parts = pl.emitter_parts() if len(pl.events) else None
+    live = np.full(max(pl.n_emitters, 1), P, dtype=np.int64) if parts is None else parts.astype(np.int64)
+    n_h = int(live[: pl.n_emitters].sum()) * C
+    st, ev = pl.streams, pl.events
+    conv = ev["n_streams"][st["event"]] > 0 if len(st) else np.zeros(0, bool)
+    n_x = int(st["n_j"][conv].sum()) if len(st) else 0
+    products = 0
+    for s_ in st[conv] if len(st) else []:
+        K, p_live = int(ev["n_blocks"][s_["event"]]), int(live[s_["emitter"]])
+        j = s_["j_lo"] + np.arange(int(s_["n_j"]))
+        products += int(np.clip(K - j, 0, p_live).sum())       # partitions p < p_live with j + p < K
+    n_y = int((C * ev["n_blocks"][ev["n_streams"] > 0]).sum())
+    mixed = int((mix_plan.slot_count.astype(np.int64) * mix_plan.slot_rows).sum()) if mix_plan is not None else 0
+    return {"al_forward_spectra": (n_h + n_x) * fft, "al_spectral_mac": products * C * B * 8.0, "al_block_synthesis": n_y * fft,
+            "al_mixdown": 2.0 * mixed}
+
+
+def secondary_roofline(pl, mix_plan, kernel_ms, valu_insts, scene_traffic, algo_bytes, dominant):
+    """SURVEY 8(d) "Bound", the honest ceiling beside the HBM fraction: achieved GFLOP/s per stage (plan-counted flops / live HIP
+    event duration) against the vector fp32 peak, the fraction of the chip's VALU issue slots each stage uses (SQ_INSTS_VALU
+    from the committed --pmc pass x 2 cycles per wave64 instruction; packed-f32 instructions occupy two slots, so this is a
+    lower bound for the accumulate), and how many bytes the step moves per algorithmic byte."""
+    flops = stage_flops(pl, mix_plan)
+    gf = {k: v / (kernel_ms[k] * 1e-3) / 1e9 for k, v in flops.items() if kernel_ms.get(k)}
+    out = {"gflops": gf.get(dominant), "gflops_by_stage": {k: round(v, 1) for k, v in gf.items()},
+           "flops_per_step": float(sum(flops.values())), "valu_peak_gflops": VALU_PEAK_TFLOPS * 1e3,
+           "valu_frac_of_peak": (gf.get(dominant) or 0.0) / (VALU_PEAK_TFLOPS * 1e3) or None,
+           "valu_issue_frac": None, "valu_issue_frac_by_stage": None,
+           "traffic_ratio": (scene_traffic / algo_bytes) if scene_traffic else None}
+    if valu_insts:
+        by = {k: valu_insts[k] / VALU_ISSUE_PER_S / (kernel_ms[k] * 1e-3) for k in valu_insts if kernel_ms.get(k) and valu_insts[k]}
+        out["valu_issue_frac"] = by.get(dominant)
+        out["valu_issue_frac_by_stage"] = {k: round(v, 4) for k, v in by.items()}
+    return out
+
+
 def load_pmc_traffic(config: str, log2_block: int):
     """(HBM bytes per launch per stage, note) from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json).
     The table carries the hash of the kernel sources it was measured on; a table from another build is refused."""
@@ -255,6 +399,18 @@ def load_pmc_traffic(config: str, log2_block: int):
         return None, (f"pmc_traffic.json was measured on kernel sources {table.get('source_hash')}, this build is "
                       f"{source_hash()}: re-run profiles/tools/collect_profiles.sh")
     return table.get(f"{config}/log2_block={log2_block}"), f"rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE, {table.get('collected', '')}"
+
+
+def load_pmc_valu(config: str, log2_block: int):
+    """SQ_INSTS_VALU per launch per stage from the same committed table (third --pmc pass), None when absent or stale."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        table = json.load(open(path))
+    except Exception:  # noqa: BLE001
+        return None
+    if table.get("source_hash") != source_hash():
+        return None
+    return table.get(f"{config}/log2_block={log2_block}/valu_insts")
 
 
 def dropin_leg(scene, renderer, n: int):
@@ -435,6 +591,10 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=-1, metavar="N",
                     help="also time the oracle on N host processes at once, one whole scene each (all-cores CPU figure; -1 = one per "
                          "PHYSICAL core, bounded by free memory; 0 = skip; skipped by itself under a profiler)")
+    ap.add_argument("--cpu-workers-sweep", default="", metavar="N1,N2,...",
+                    help="CPU-only mode (no GPU is touched): the all-cores oracle leg at each of these worker counts, with and without "
+                         "the reference's per-event padded copies, one JSON line {workers_sweep, cpu_quota, knee}; what explains "
+                         "profiles/r04a's 30x per-process slowdown at 128 workers")
     ap.add_argument("--cpu-scene-events", type=int, default=-1, metavar="N",
                     help="events of every scene the all-cores leg renders (-1: a bounded sample, 6 for cfg2; 0: the whole scene, "
                          "which takes 128 busy cores about nine minutes at cfg2)")
@@ -454,6 +614,9 @@ def main():
     ap.add_argument("--no-gather", dest="gather", action="store_false")
     args = ap.parse_args()
 
+    if args.cpu_workers_sweep:
+        print(json.dumps(cpu_workers_sweep(args)), flush=True)
+        return
     if "RANK" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args.gpus))   # nothing in this process has touched the GPU yet
     rank = int(os.environ.get("RANK", "0"))
@@ -517,6 +680,15 @@ def main():
             dist.init_process_group(backend)
     new_event, device_sync = make_timers(emulate, torch)
     coll_dev = "cuda" if (backend == "nccl" and not emulate) else "cpu"
+    # N ranks on one node: each takes its share of the host (helper pools capped at usable CPUs / local ranks, the process pinned
+    # to the CPUs next to its GPU) instead of sizing planner / cast / pack pools for the whole machine N times over
+    host_share = None
+    if use_dist:
+        from audiblelight_amd import distributed as _dist_mod, engine as _engine_mod
+
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        host_share = _dist_mod.host_share(local_rank, local_world, None if emulate else local_rank, pin=world > 1)
+        _engine_mod.set_thread_cap(host_share["threads"])
 
     def barrier():
         device_sync()
@@ -540,7 +712,7 @@ def main():
         return [float(v.item()) for v in t]
 
     ctx = dict(args=args, rank=rank, world=world, emulate=emulate, torch=torch, dist=dist, use_dist=use_dist, backend=backend,
-               all_cores=all_cores,
+               all_cores=all_cores, host_share=host_share,
                new_event=new_event, device_sync=device_sync, barrier=barrier, reduce_max=reduce_max, all_ranks=all_ranks)
     if args.shard == "capsules":
         out = run_capsule_sharded_mode(ctx)
@@ -549,6 +721,12 @@ def main():
     else:
         out = run_scene_per_rank_mode(ctx)
     failed = bool(out.pop("_failed", False))
+    if host_share is not None:
+        threads = all_ranks(float(host_share["threads"]))
+        nodes = all_ranks(float(-1 if host_share["numa_node"] is None else host_share["numa_node"]))
+        out["host_share"] = dict(host_share, threads_by_rank=[int(x) for x in threads], numa_node_by_rank=[int(x) for x in nodes],
+                                 note="helper pools of every rank capped at usable CPUs / local ranks; with N > 1 the process is pinned "
+                                      "to the CPUs local to its GPU's NUMA node (audiblelight_amd/distributed.py::host_share)")
     if rank == 0:
         print(json.dumps(out), flush=True)
     if use_dist:
@@ -655,6 +833,10 @@ def run_scene_per_rank_mode(ctx):
                        "scene_traffic": sum(v for v in (pmc or {}).values() if isinstance(v, (int, float))) or None,
                        "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": kernel_ms,
                        "hbm_bytes_per_launch_pmc": pmc}
+    if not chunked:
+        out["roofline"].update(secondary_roofline(
+            pl, mix_plan, kernel_ms, load_pmc_valu(scene.name, pl.log2_block) if args.scale == 1.0 else None,
+            out["roofline"]["scene_traffic"], algo_bytes, dominant))
     if args.other_configs and world == 1 and not emulate and args.config == "cfg2" and args.scale == 1.0:
         out["other_configs"] = other_configs_leg(ctx, r)
         if any(not v.get("parity", {}).get("ok", True) for v in out["other_configs"].values()):
@@ -749,6 +931,8 @@ def other_configs_leg(ctx, r):
                      "kernel_ms": {k: round(v, 4) for k, v in kernel_ms.items()},
                      "inputs": "clips drawn on the host, IR tensor on the device (same law)",
                      "setup_s": None}
+        sec = secondary_roofline(pl, mix_plan, kernel_ms, load_pmc_valu(name, pl.log2_block), out[name]["traffic"], algo, dominant)
+        out[name].update({k: sec[k] for k in ("gflops", "valu_frac_of_peak", "valu_issue_frac", "traffic_ratio")})
         if args.parity_events != 0:
             # a bounded number of events of THIS render against the oracle, every IR, all capsule rows x all scene samples
             n_par = {"cfg3": 1, "cfg4": 4, "cfg5": 2}[name]
@@ -807,6 +991,12 @@ def gather_and_validate(ctx, r, mine, rerender_fn, n_items=None, local=None):
     if rank == 0:
         ok = sorted(got) == list(range(n_items))
         rec["bytes_total"] = int(sum(v.numel() * 4 for v in got.values()))
+        # what crossed the links: everything but rank 0's own items; every peer sends over ITS OWN xGMI link into the root, so the
+        # per-link rate is the aggregate divided by the peers (to hold against ~153 GB/s per link, MI355X_MICROARCH.md)
+        moved = int(sum(v.numel() * 4 for i, v in got.items() if i % world != 0))
+        rec["bytes_over_links"] = moved
+        rec["GBps_into_root"] = moved / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None
+        rec["GBps_per_peer_link"] = (moved / max(world - 1, 1)) / (g_ms * 1e-3) / 1e9 if (g_ms > 0 and world > 1) else None
         checked = {}
         for item in sorted({i for i in (1, n_items - 1) if 0 < i < n_items and i % world != 0}):
             want = rerender_fn(item)

@@ -8,16 +8,18 @@ rm -f $R/gpurun_out/${TAG}_pmc_traffic.json
 for CFG in $CONFIGS; do
   case $CFG in cfg2|cfg4) PS=3; SS=50;; *) PS=2; SS=10;; esac
   case $CFG in cfg5) LB=14;; *) LB=13;; esac     # the planner's block size for the config (bench.py looks the traffic up under it)
-  for c in FETCH_SIZE WRITE_SIZE; do
+  for c in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rocprofv3 --kernel-trace --pmc $c --output-format csv -d $R/gpurun_out/${TAG}_${CFG}_pmc_$c -- python3 $R/bench.py --config $CFG --steps $PS --warmup 1 $QUIET > $R/gpurun_out/${TAG}_${CFG}_pmc_$c.log 2>&1; echo "$CFG $c rc=$?"
   done
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${CFG}_stats -- python3 $R/bench.py --config $CFG --steps $SS --warmup 3 $QUIET > $R/gpurun_out/${TAG}_${CFG}_stats.log 2>&1; echo "$CFG stats rc=$?"
   cd $R
   F=$(find gpurun_out/${TAG}_${CFG}_pmc_FETCH_SIZE -name '*counter_collection.csv' | head -1); W=$(find gpurun_out/${TAG}_${CFG}_pmc_WRITE_SIZE -name '*counter_collection.csv' | head -1)
-  python3 profiles/tools/summarise_pmc.py $F $W $CFG/log2_block=$LB gpurun_out/${TAG}_pmc_traffic.json > /dev/null; echo "$CFG summarise rc=$?"
+  V=$(find gpurun_out/${TAG}_${CFG}_pmc_SQ_INSTS_VALU -name '*counter_collection.csv' | head -1)
+  python3 profiles/tools/summarise_pmc.py $F $W $CFG/log2_block=$LB gpurun_out/${TAG}_pmc_traffic.json $V > /dev/null; echo "$CFG summarise rc=$?"
   python3 profiles/tools/slim_pmc_csv.py $F gpurun_out/${TAG}_${CFG}_pmc_fetch_size.csv; python3 profiles/tools/slim_pmc_csv.py $W gpurun_out/${TAG}_${CFG}_pmc_write_size.csv
   cp $(find gpurun_out/${TAG}_${CFG}_stats -name '*kernel_stats.csv' | head -1) gpurun_out/${TAG}_${CFG}_kernel_stats.csv
-  rm -rf gpurun_out/${TAG}_${CFG}_pmc_FETCH_SIZE gpurun_out/${TAG}_${CFG}_pmc_WRITE_SIZE gpurun_out/${TAG}_${CFG}_stats
+  python3 profiles/tools/slim_pmc_csv.py $V gpurun_out/${TAG}_${CFG}_pmc_valu_insts.csv
+  rm -rf gpurun_out/${TAG}_${CFG}_pmc_FETCH_SIZE gpurun_out/${TAG}_${CFG}_pmc_WRITE_SIZE gpurun_out/${TAG}_${CFG}_pmc_SQ_INSTS_VALU gpurun_out/${TAG}_${CFG}_stats
   cd /tmp
 done
 cd $R

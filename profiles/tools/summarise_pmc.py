@@ -3,7 +3,9 @@
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md "HBM"): FETCH_SIZE reports exactly
 half of the bytes of a wide coalesced streaming read (8-16 B/lane loads here), so it is doubled; WRITE_SIZE is exact.
-    python profiles/tools/summarise_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key> [out.json]
+    python profiles/tools/summarise_pmc.py <fetch_counter_collection.csv> <write_counter_collection.csv> <key> [out.json] [valu_counter_collection.csv]
+The optional third pass (--pmc SQ_INSTS_VALU) adds "<key>/valu_insts": wave64 VALU instructions per launch per stage, from which
+bench.py derives roofline.valu_issue_frac.
 """
 import collections
 import csv
@@ -46,6 +48,9 @@ def main():
     table["collected"] = datetime.date.today().isoformat()
     table[key] = {k: int(2 * f.get(k, 0) * 1024 + w.get(k, 0) * 1024) for k in NAMES.values()}
     table[key + "/detail"] = {k: {"fetch_KiB_raw": f.get(k, 0), "write_KiB": w.get(k, 0)} for k in NAMES.values()}
+    if len(sys.argv) > 5:
+        v = per_kernel(sys.argv[5], "SQ_INSTS_VALU")
+        table[key + "/valu_insts"] = {k: int(v.get(k, 0)) for k in NAMES.values()}
     json.dump(table, open(out, "w"), indent=1)
     print(json.dumps(table[key], indent=1))
 

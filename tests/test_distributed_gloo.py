@@ -18,10 +18,10 @@ WORKER = textwrap.dedent("""
     from audiblelight_amd import _hip, distributed, engine, plan as planning
     from tests import hostemu
 
-    def render(i, r):
+    def render(i, r, equal=False):
         rng = np.random.default_rng(100 + i)
-        C, L, sr = 2 + i % 2, 300, 8000          # ragged: capsule count differs between scenes
-        n = 900 + 50 * i
+        C, L, sr = 2 + (0 if equal else i % 2), 300, 8000          # ragged: capsule count differs between scenes
+        n = 900 + (0 if equal else 50 * i)
         a = rng.standard_normal(n).astype(np.float32)
         h = rng.standard_normal((C, 1, L)).astype(np.float32)
         pl = planning.plan_batch([planning.EventSpec(n_samples=n, n_emitters=1, snr=10.0)], C, L, sr, log2_block=10)
@@ -39,6 +39,25 @@ WORKER = textwrap.dedent("""
         np.save({out!r}, np.array([out[i].sum() for i in range(5)]))
     else:
         assert out is None
+    # the same collection on the OTHER rank, and the overlapped form (every scene sent the moment it is rendered) with a scene
+    # count that is not a multiple of the world: rank 1 receives scenes 0 and 2 from rank 0 and keeps its own scene 1
+    rank = dist.get_rank()
+    out = distributed.render_scenes(5, lambda i: render(i, r), gather=True, dst=1)
+    assert (out is None) == (rank != 1)
+    if rank == 1:
+        for i in range(5):
+            np.testing.assert_array_equal(out[i], render(i, r))
+    shape = render(0, r, equal=True).shape
+    got = distributed.render_and_gather_overlapped(lambda i: render(i, r, equal=True), 3, shape, dst=1)
+    assert (got is None) == (rank != 1)
+    if rank == 1:
+        assert sorted(got) == [0, 1, 2]
+        for i in range(3):
+            np.testing.assert_array_equal(got[i].numpy(), render(i, r, equal=True))
+    # this rank's share of the host: half the usable CPUs as the cap of any helper pool, and the process pinned to its half
+    before = len(os.sched_getaffinity(0))
+    share = distributed.host_share(rank, 2, None, pin=True)
+    assert share["threads"] == max(1, before // 2) and share["pinned"] and len(os.sched_getaffinity(0)) == share["cpus"] == max(1, before // 2)
     dist.destroy_process_group()
 """)
 

@@ -391,7 +391,9 @@ def test_bench_collectives_on_rccl_with_one_rank():
     # the other two modes on the same backend: a batch of scenes all gathered, one scene with its capsules "sharded" over one rank
     common = [sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "5", "--repeats", "1", "--cpu-events", "0",
               "--cpu-workers", "0"]
-    for extra, check in ((["--total-scenes", "3"], lambda o: o["config"]["total_scenes"] == 3 and o["gather"]["bytes_total"] == 3 * 4 * 4 * 240000),
+    for extra, check in ((["--total-scenes", "3"], lambda o: o["config"]["total_scenes"] == 3 and o["gather"]["bytes_total"] == 3 * 4 * 4 * 240000
+                          and o["gather"]["overlapped"]["bit_exact"] and o["gather"]["overlapped"]["step_with_gather_ms"] > 0
+                          and o["host_share"]["threads_by_rank"] == [o["host_share"]["threads"]] and not o["host_share"]["pinned"]),
                          (["--shard", "capsules"], lambda o: o["config"]["capsules_this_rank"] == 4 and o["gather"]["within_tolerance"])):
         res = subprocess.run(common + extra, env=env, capture_output=True, text=True, timeout=600)
         assert res.returncode == 0, res.stderr[-2000:]

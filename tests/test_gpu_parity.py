@@ -208,6 +208,42 @@ def test_full_size_properties(gpu, planning, name):
         assert_parity(scene6[row], ref6[row], TOL, what=row)
 
 
+def test_cfg2_full_scene_vs_oracle(gpu, planning):
+    """The headline workload in full against the oracle: BASELINE configs[1] -- 64 events x 32 capsules x 2 s RIRs, 60 s at
+    48 kHz -- rendered and mixed through the default dispatch (the configuration bench.py times) and compared with the oracle's
+    scene of ALL 64 events, every capsule row x all 2 880 000 samples, both halves of the 1e-4 bound; every event's level-law
+    scalar against the oracle's as well.  (bench.py makes the same comparison on the buffer its timed steps wrote: JSON key
+    `parity`.)  Reference: synthesize.py:613-677 then :314-401."""
+    from audiblelight_amd import synthetic
+
+    sc = synthetic.make_scene("cfg2")
+    pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr, lib=gpu.lib)
+    batch = gpu.prepare(pl, sc.clips, sc.irs)
+    import ctypes as ct
+    code, mcode = ct.c_int32(), ct.c_int32()
+    gpu.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(code), ct.byref(mcode))
+    assert (pl.log2_block, code.value) == (13, 3121202)          # split layout, k_spectral_mac_static<12,12,2>
+    res = batch.run()
+    res.check_finite()
+    n = len(sc.clips)
+    mix = planning.plan_mixdown(sc.starts, sc.ends, [len(c) for c in sc.clips], [sc.n_capsules] * n, pl.events["out_off"],
+                                list(range(n)), sc.duration, sc.sr, sc.n_capsules, lib=gpu.lib)
+    scene = gpu.mem.download(gpu.mixdown(mix, res))[: sc.n_capsules * mix.n_samples].reshape(sc.n_capsules, -1)
+    scales = res.scales()
+    ref = np.zeros((sc.n_capsules, mix.n_samples), dtype=np.float32)
+    for e in range(n):          # one event at a time: the oracle's float64 (32, 192 000) render is 49 MB
+        out = orc.render_event(sc.clips[e], sc.irs[:, [e], :].astype(np.float64), sc.specs[e].snr, sc.specs[e].ref_db, sr=sc.sr)
+        a0, b0 = orc.event_slot(sc.starts[e], sc.ends[e], sc.sr, mix.n_samples)
+        ref[:, a0:b0] += orc.fit_length(out["spatial"], b0 - a0)
+        # total multiplier of the raw convolution: unit_energy gain cancels in the level law for static events (SURVEY A9)
+        assert scales[e] * res.stats()[e, 0] / (sc.n_capsules * sc.specs[e].n_samples) == pytest.approx(
+            10 ** ((sc.specs[e].ref_db + sc.specs[e].snr) / 20), rel=1e-5)
+    assert scene.shape == ref.shape == (32, 2_880_000)
+    assert_parity(scene, ref, TOL, what="cfg2 scene, 64 events")
+    for row in range(sc.n_capsules):
+        assert_parity(scene[row], ref[row], TOL, what=row)
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_batches_vs_oracle(gpu, planning, seed, monkeypatch):
     """Seeded random batches (static / moving / zero-emitter events, ragged lengths, every block size, runs of blocks

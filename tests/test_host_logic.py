@@ -205,7 +205,7 @@ def test_bench_line_carries_parity_of_what_it_timed():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK") and not k.startswith("AL_")}
     env.update(AL_BENCH_EMULATE="1")
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0", "--repeats", "1", "--config", "cfg2",
-           "--scale", "0.02", "--cpu-workers", "0", "--end-to-end", "0", "--dropin", "0"]
+           "--scale", "0.005", "--cpu-workers", "0", "--end-to-end", "0", "--dropin", "0"]
 
     def run(extra, **more_env):
         res = subprocess.run(cmd + extra, env=dict(env, **more_env), capture_output=True, text=True, timeout=900)
@@ -214,14 +214,13 @@ def test_bench_line_carries_parity_of_what_it_timed():
 
     out = run(["--cpu-events", "64"])
     par = out["parity"]
-    assert par["ok"] and par["events"] == 64 and par["rows"] == 32 and par["samples"] == round(60 * 0.02 * 48000)
+    assert par["ok"] and par["events"] == 64 and par["rows"] == 32 and par["samples"] == round(60 * 0.005 * 48000)
     assert 0 < par["rel_rms"] < 1e-5 and 0 < par["max_abs_over_peak"] < 1e-5 and par["tol"] == 1e-4
     assert "timed steps wrote" in par["note"] and out["config"]["switches"] == {}
     assert out["cpu_baseline"]["extrapolated"] is False
     out = run(["--cpu-events", "2", "--parity-events", "5"], AL_STATIC_MAC="0")
     assert out["parity"]["ok"] and out["parity"]["events"] == 5 and "first 5 of 64" in out["parity"]["note"]
     assert out["config"]["switches"] == {"static_mac": False}
-    assert "parity" not in run(["--cpu-events", "0", "--parity-events", "0"])
 
 
 def test_bench_eight_ranks_scene_batch_index_arithmetic():
@@ -256,6 +255,11 @@ def test_bench_eight_ranks_scene_batch_index_arithmetic():
     assert g["ranks_seen"] == list(range(8)) and g["bytes_total"] == 19 * (4 * 12000 * 4)
     assert g["validated_against_local_rerender"] == {"1": True, "18": True} and g["bit_exact"] and g["overlapped"]["bit_exact"]
     assert len(out["timing"]["ms_per_step_by_rank_last_repeat"]) == 8
+    # every rank took its share of the host: helper pools capped at usable CPUs / 8, the process pinned to that many CPUs
+    cpus = len(os.sched_getaffinity(0))
+    hs = out["host_share"]
+    assert hs["threads_by_rank"] == [max(1, cpus // 8)] * 8 and hs["pinned"] and hs["cpus"] == max(1, cpus // 8)
+    assert g["bytes_over_links"] == (19 - 3) * (4 * 12000 * 4) and g["GBps_into_root"] > 0 and g["GBps_per_peer_link"] > 0
     weak8, one = run(["--gpus", "8"]), run(["--gpus", "1"])
     assert weak8["n_gpus"] == 8 and weak8["gather"]["ranks_seen"] == list(range(8)) and weak8["gather"]["bit_exact"]
     assert weak8["gather"]["validated_against_local_rerender"] == {"1": True, "7": True}

@@ -649,6 +649,14 @@ def main():
 
             cores, how = physical_cores()
             workers = cores if args.cpu_workers < 0 else args.cpu_workers
+            # the container's CPU QUOTA, not the CPUs it can see, is what "all cores" can mean here: the pool's boxes show 256 CPUs
+            # under cpu.max = 16 CPUs, and 128 runnable processes on a 16-CPU quota are throttled into a 30x per-process slowdown
+            # (profiles/r05b_cpu_workers_sweep.json: the aggregate rate peaks AT the quota -- 44 scene-s/s with 16 workers -- and
+            # falls to 15 with 128).  One worker per allowed CPU unless --cpu-workers names a count.
+            quota = cpu_quota()["cpus_allowed_by_quota"]
+            if args.cpu_workers < 0 and quota:
+                workers = max(1, min(workers, int(quota)))
+                how += f"; capped at the cgroup CPU quota of {quota:g} CPUs (cpu.max)"
             cfg = synthetic.CONFIGS[args.config]
             try:   # every worker holds one scene's IR tensor, three scene-sized buffers and one event's float64 temporaries:
                    # stay inside half the free memory (a box that runs out of memory dies without a message)

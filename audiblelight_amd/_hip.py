@@ -18,14 +18,11 @@ AL_OK, AL_E_BADARG, AL_E_HIP, AL_E_UNSUPPORTED = 0, -1, -2, -3
 ABI_VERSION = 6   # AL_ABI_VERSION of include/audiblelight_hip.h these struct mirrors were written against
 MIN_LOG2_BLOCK, MAX_LOG2_BLOCK = 10, 14
 FLAG_NO_IR_NORM = 1
-FLAG_FUSED_STATIC = 2
 FLAG_SPLIT_SPECTRA = 32
 FLAG_STATIC_MAC = 64
 FLAG_ONLY_STATIC = 128
 FLAG_NARROW_FFT = 4
 FLAG_QUAD_SPECTRA = 256
-FLAG_FUSED_MOVING = 512
-FLAG_FUSED_NJ5 = 1024
 # bits of al_batch.flags that only pick between equivalent code paths (narrow FFT, runs of blocks per workgroup)
 DEBUG_FLAG_MASK = FLAG_NARROW_FFT | (7 << 12) | (0xff << 16) | (0x7f << 24)   # bit 12: static accumulate, one k-tile per workgroup
 
@@ -120,8 +117,6 @@ SYMBOLS = {
     "al_signal_spectra": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
-    "al_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
-    "al_moving_fused_supported": (ct.c_int, [ct.POINTER(AlBatch)]),
     "al_plan_last_error": (ct.c_char_p, []),
     "al_choose_log2_block": (ct.c_int32, [ct.c_int32, ct.c_int32]),
     "al_stft_frame_count": (ct.c_int32, [ct.c_int64, ct.c_int32]),
@@ -137,13 +132,12 @@ SYMBOLS = {
     "al_plan_audio_offsets": (ct.c_void_p, [_P]),
     "al_workspace_bytes": (ct.c_int64, [_P]),
     "al_plan_chunk": (ct.c_int, [_P, ct.c_int32, ct.c_int32, ct.POINTER(AlChunk)]),
-    "al_plan_emitter_parts": (ct.c_int, [_P, ct.c_int32, _P]),
+    "al_plan_emitter_parts": (ct.c_int, [_P, _P]),
     "al_plan_batch_flags": (ct.c_int, [_P, ct.POINTER(AlChunk), ct.POINTER(ct.c_int32)]),
     "al_plan_mixdown": (ct.c_int, [_P, _P, _P, _P, _P, _P, ct.c_int32, ct.c_double, ct.c_double, ct.c_int32, ct.c_int32,
                                    ct.POINTER(ct.c_void_p)]),
     "al_mix_plan_destroy": (None, [_P]),
     "al_mix_plan_get": (ct.c_int, [_P, ct.POINTER(AlMixTables)]),
-    "al_mac_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_block_synthesis": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_levels": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_event_stats": (ct.c_int, [ct.POINTER(AlBatch), _S]),

@@ -86,35 +86,9 @@ __device__ __forceinline__ float2 stream_load(const float2 *p) {
   return *p;
 }
 
-// Blocks of M complex bins behind `base`, read 16 bytes per lane through a buffer descriptor: the block and column
-// offsets are SCALAR (soffset), the only vector register is the lane's byte offset.  `poison` makes every lane's
-// offset fall outside the descriptor's range, for which the hardware returns 0.
-struct SpectraView {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __amdgpu_buffer_rsrc_t rsrc;
-  __device__ __forceinline__ SpectraView(const float2 *base, int n_blocks, int M)
-      : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<float2 *>(base), 0, n_blocks * M * 8, 0x00020000)) {}
-  __device__ __forceinline__ float4 load(int byte_offset, int lane_bytes) const {
-    typedef int v4i __attribute__((ext_vector_type(4)));
-    const v4i v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_bytes, byte_offset, 0);
-    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
-  }
-#else
-  const char *base;
-  int64_t n_bytes;
-  __device__ __forceinline__ SpectraView(const float2 *b, int n, int M)
-      : base(reinterpret_cast<const char *>(b)), n_bytes((int64_t)n * M * 8) {}
-  __device__ __forceinline__ float4 load(int byte_offset, int lane_bytes) const {
-    if ((unsigned)lane_bytes >= (uint64_t)n_bytes) return make_float4(0.f, 0.f, 0.f, 0.f);
-    return *reinterpret_cast<const float4 *>(base + (unsigned)byte_offset + lane_bytes);
-  }
-#endif
-};
-constexpr int SPECTRA_POISON = (int)0x80000000u;
-
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence: hipcc puts s_waitcnt vmcnt(0) in
 // front of its s_barrier, which drains every global load in flight -- a kernel that requests data a phase ahead of its use
-// (k_moving_fused: the next round's samples during this round's products) would wait for it at the very next barrier.  Here only
+// (the quad-tile transforms of al_quad16.h: the next partition during this one's transforms) would wait for it at the very next barrier.  Here only
 // the LDS counter is waited on; registers loaded from global memory are still guarded by the waits hipcc inserts at their use.
 template <bool LDS_ONLY>
 __device__ __forceinline__ void block_barrier() {
@@ -165,8 +139,5 @@ hipError_t launch_ir_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_forward_spectra(const al_batch *b, hipStream_t stream);
 hipError_t launch_block_synthesis(const al_batch *b, hipStream_t stream);
-hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream);
-hipError_t launch_moving_fused(const al_batch *b, hipStream_t stream);   // csrc/al_quad.h
-int moving_fused_code(const al_batch *b);
 
 }  // namespace al

@@ -409,42 +409,12 @@ __device__ __forceinline__ void fft_regs_to_regs(float2 (&v)[G::E], float2 *s, c
 
 // ---- where slot q of a spectrum half lives
 // PlainSlots: at q (the layouts of DESIGN.md sections 2 and 5.2).
-// QuadSlots<M>: the "quad" layout of csrc/al_quad.h for the split kernels (M = B/2 slots per half, Q = M/2): every half is
-// stored as two tiles of Q slots, each of which is a plain Q-point complex transform of the (folded, twisted) window -- so a
-// workgroup that owns ONE tile can make its own slice of an IR partition's spectrum from the raw samples:
-//   even half (E[q] = W[2q], q < M):  T0[i] = E[2i]            (slot 0 still packs W[0] and W[B])
-//                                     T1[i] = E[4i + 1], i < Q  (for 4i + 1 > M the VALUE of that bin, i.e. the conjugate
-//                                             of the stored E[2M - 4i - 1]; slots q = 3 mod 4 land there conjugated)
-//   odd half  (U[q] = W[4q + 1]):     T2[i] = U[2i],  T3[i] = U[2i + 1]
-// The accumulate is element-wise on slots, so any consistent permutation (+ conjugation) of X, H and Y is transparent to it.
 struct PlainSlots {
   static __device__ __forceinline__ void store_even(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }
   static __device__ __forceinline__ void store_odd(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }
   static __device__ __forceinline__ float2 load_even(const float2 *half, int q) { return stream_load<2>(half + q); }
   static __device__ __forceinline__ float2 load_odd(const float2 *half, int q) { return stream_load<2>(half + q); }
 };
-template <int M>
-struct QuadSlots {
-  static constexpr int Q = M / 2;
-  static __device__ __forceinline__ int even_slot(int q, bool &conj) {
-    conj = (q & 3) == 3;
-    return (q & 1) == 0 ? (q >> 1) : (conj ? Q + ((2 * M - q - 1) >> 2) : Q + ((q - 1) >> 2));
-  }
-  static __device__ __forceinline__ int odd_slot(int q) { return (q & 1) ? Q + (q >> 1) : (q >> 1); }
-  static __device__ __forceinline__ void store_even(float2 *half, int q, float2 v) {
-    bool cj;
-    const int d = even_slot(q, cj);
-    half[d] = cj ? make_float2(v.x, -v.y) : v;
-  }
-  static __device__ __forceinline__ void store_odd(float2 *half, int q, float2 v) { half[odd_slot(q)] = v; }
-  static __device__ __forceinline__ float2 load_even(const float2 *half, int q) {
-    bool cj;
-    const float2 v = half[even_slot(q, cj)];
-    return cj ? make_float2(v.x, -v.y) : v;
-  }
-  static __device__ __forceinline__ float2 load_odd(const float2 *half, int q) { return half[odd_slot(q)]; }
-};
-
 // ---- real <-> half-complex packing around the M-point complex transform (N = 2M real samples)
 // Forward: Z = FFT_M(x[2n] + i x[2n+1]);  X[k] = E + w^k O,  X[M-k] = conj(E - w^k O),
 //   E = (Z[k] + conj Z[M-k])/2,  O = -i (Z[k] - conj Z[M-k])/2,  w = exp(-i*pi/M).

@@ -137,7 +137,7 @@ __device__ __forceinline__ void spectral_mac_body(const al_batch &b) {
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (ev.n_streams <= 0) return;
   if (ev.n_streams > 1 && ev.reserved == 1 && b.n_partitions <= AL_SPARSE_MAX_PARTITIONS) return;  // k_spectral_mac_moving
-  if (ev.n_streams == 1 && ((b.flags & AL_FLAG_FUSED_STATIC) || static_mac_active(b))) return;     // k_mac_synthesis / k_spectral_mac_static
+  if (ev.n_streams == 1 && static_mac_active(b)) return;     // k_spectral_mac_static
   const float2 *__restrict__ X = reinterpret_cast<const float2 *>(b.xspec);
   const float2 *__restrict__ H = reinterpret_cast<const float2 *>(b.hspec);
   float2 *__restrict__ Y = reinterpret_cast<float2 *>(b.yspec);
@@ -1266,8 +1266,7 @@ MacPlan plan_mac(const al_batch *b) {
   else m.tile_code = 80401;
   // moving events flagged by the planner (al_event.reserved == 1: every stream has n_j <= AL_SPARSE_MAX_NJ)
   if (b->n_streams > b->n_events && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS)
-    m.moving_code = (b->flags & AL_FLAG_FUSED_MOVING) ? al::moving_fused_code(b)
-                                                      : 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
+    m.moving_code = 100 * AL_SPARSE_MAX_NJ + (b->n_partitions <= 12 ? 12 : AL_SPARSE_MAX_PARTITIONS);
   m.static_code = m.tile_code;
   if (al::static_mac_active(*b)) {
     const int P = b->n_partitions;
@@ -1457,10 +1456,6 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
 #undef AL_MAC
 #undef AL_MAC_KS
   if (int rc = check_launch("k_spectral_mac")) return rc;
-  if (m.moving_code >= 10000) {
-    if (!al_moving_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_MOVING needs B = 8192 and the split + quad layout flags");
-    return check_error(al::launch_moving_fused(b, stream), "k_moving_fused");
-  }
   if (m.moving_code) {
     const dim3 grid(bins / 256, b->n_capsules, b->n_events);
     if (m.moving_code % 100 == 12)
@@ -1471,27 +1466,6 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream_) {
     return check_launch("k_spectral_mac_moving");
   }
   return AL_OK;
-}
-
-int al_fused_supported(const al_batch *b) {
-  if (check_batch(b)) return 0;
-  // the fused kernel addresses the signal spectra with 32-bit byte offsets from the workspace base
-  return b->log2_block == 13 && b->xspec_zero_block >= 0 && b->xspec_zero_block < 65535 && b->hspec_zero_block >= 0 &&
-         b->n_emitters > 0 && b->n_events > 0 && b->n_partitions < 32768;
-}
-
-int al_moving_fused_supported(const al_batch *b) {
-  if (check_batch(b)) return 0;
-  return b->log2_block == 13 && b->n_partitions >= 1 && b->n_partitions <= AL_SPARSE_MAX_PARTITIONS &&
-         (b->flags & AL_FLAG_SPLIT_SPECTRA) && (b->flags & AL_FLAG_QUAD_SPECTRA) && !(b->flags & AL_FLAG_FUSED_STATIC);
-}
-
-int al_mac_synthesis(const al_batch *b, al_stream_t stream) {
-  if (int rc = check_batch(b)) return rc;
-  if (!(b->flags & AL_FLAG_FUSED_STATIC)) return AL_OK;
-  if (!al_fused_supported(b)) return fail(AL_E_UNSUPPORTED, "AL_FLAG_FUSED_STATIC needs B = 8192 and the zero blocks");
-  if (b->n_events <= 0 || b->max_blocks <= 0) return AL_OK;
-  return check_error(al::launch_mac_synthesis(b, (hipStream_t)stream), "k_mac_synthesis");
 }
 
 int al_block_synthesis(const al_batch *b, al_stream_t stream) {
@@ -1527,7 +1501,6 @@ int al_render_batch(const al_batch *b, al_stream_t stream) {
   if ((rc = al_forward_spectra(b, stream))) return rc;
   if ((rc = al_emitter_gains(b, stream))) return rc;
   if ((rc = al_spectral_mac(b, stream))) return rc;
-  if ((rc = al_mac_synthesis(b, stream))) return rc;
   if ((rc = al_block_synthesis(b, stream))) return rc;
   return al_event_levels(b, stream);
 }

@@ -320,16 +320,15 @@ int al_plan_batch_flags(const al_plan *p, const al_chunk *chunk, int32_t *flags)
 }
 
 // al_batch.emitter_parts for the whole plan.  Returns 1 and fills out[n_emitters] when the batch needs the table (some IR has
-// partitions no kept block hears, or -- fused_moving != 0 -- some IR column is heard only by sliding-window events and is
-// therefore transformed by k_moving_fused itself: 0 = "energy only"), 0 when every IR needs all its partitions (out untouched).
-int al_plan_emitter_parts(const al_plan *p, int32_t fused_moving, int32_t *out) {
+// partitions no kept block hears), 0 when every IR needs all its partitions (out untouched).
+int al_plan_emitter_parts(const al_plan *p, int32_t *out) {
   if (!p || !out) return plan_fail(AL_E_BADARG, "null plan");
   const int32_t P = p->n_partitions(), N = p->n_emitters;
   bool any_sliding = false;
   for (const al_event &e : p->events) any_sliding |= e.reserved == 1;
   if (P < 1 || N < 1 || p->streams.empty() || !any_sliding) return 0;
   std::vector<int32_t> need(N, 0);
-  std::vector<char> used(N, 0), fused(N, 0), other(N, 0);
+  std::vector<char> used(N, 0);
   const bool trim = P > 1 && P <= AL_SPARSE_MAX_PARTITIONS;
   for (const al_stream &s : p->streams) {
     const al_event &e = p->events[s.event];
@@ -339,16 +338,12 @@ int al_plan_emitter_parts(const al_plan *p, int32_t fused_moving, int32_t *out) 
     if (e.reserved == 1) {
       const int32_t reach = std::min(std::max(e.n_blocks - s.j_lo, 0), P);
       want = trim ? (s.n_j > 0 ? reach : 0) : P;
-      fused[s.emitter] = 1;
-    } else {
-      other[s.emitter] = 1;
     }
     need[s.emitter] = std::max(need[s.emitter], want);
   }
   bool any = false;
   for (int n = 0; n < N; ++n) {
     if (!used[n]) need[n] = P;
-    if (fused_moving && fused[n] && !other[n]) need[n] = 0;
     any |= need[n] < P;
   }
   if (!any) return 0;

@@ -17,7 +17,7 @@
 
 #include "al_common.h"
 #include "al_fft.h"
-#include "al_fused.h"   // synth_store_block
+#include "al_synth_store.h"
 
 #ifndef AL_SPLIT_WAVES
 #define AL_SPLIT_WAVES 3   /* minimum waves per SIMD the split kernels are compiled for (register budget) */
@@ -66,10 +66,10 @@ __device__ __forceinline__ void split_odd_input(const float2 (&d)[G::E], float2 
 }
 
 // ------------------------------------------------------------------ 1s. IR partition spectra, split layout
-template <int LOG2M, bool QUAD>
+template <int LOG2M>
 __device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 *s, float *red, int p, int c, int nz) {
   using G = FftGeom<LOG2M - 1, 16>;
-  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
+  using L = PlainSlots;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   const int tid = threadIdx.x;
   const int n = b.emitter0 + nz;
@@ -122,18 +122,18 @@ __device__ __forceinline__ void ir_spectra_split_body(const al_batch &b, float2 
   if (tid == 0) b.ir_energy[blk] = energy;
 }
 
-template <int LOG2M, bool QUAD = false>
+template <int LOG2M>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_ir_spectra_split(al_batch b) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
   __shared__ float red[48];
-  ir_spectra_split_body<LOG2M, QUAD>(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
+  ir_spectra_split_body<LOG2M>(b, s, red, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ------------------------------------------------------------------ 3s. signal block spectra, split layout
-template <int LOG2M, bool QUAD>
+template <int LOG2M>
 __device__ __forceinline__ void signal_spectra_split_body(const al_batch &b, float2 *s, int jblock, int stream_index) {
   using G = FftGeom<LOG2M - 1, 16>;
-  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
+  using L = PlainSlots;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   const int tid = threadIdx.x;
   const al_stream st = b.streams[b.stream0 + stream_index];
@@ -190,44 +190,43 @@ __device__ __forceinline__ void signal_spectra_split_body(const al_batch &b, flo
     fft_regs_to_regs<G, -1>(u, s, tw, tid);
 #pragma unroll
     for (int i = 0; i < E; ++i) {
-      if constexpr (QUAD) L::store_odd(out + M, tid + T * i, u[i]);
-      else out[M + tid + T * i] = u[i];
+      out[M + tid + T * i] = u[i];
     }
   }
   fft_regs_to_regs<G, -1>(h1, s, tw, tid);
   real_unpack_store_regs<G, L>(h1, s, tw.w0, tid, out);
 }
 
-template <int LOG2M, bool QUAD = false>
+template <int LOG2M>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_signal_spectra_split(al_batch b) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
-  signal_spectra_split_body<LOG2M, QUAD>(b, s, blockIdx.x, blockIdx.y);
+  signal_spectra_split_body<LOG2M>(b, s, blockIdx.x, blockIdx.y);
 }
 
 // Both forward transforms in ONE launch (they are independent): the 1 536 signal windows of a cfg2 scene are a 0.05 ms
 // kernel of their own otherwise, too short to fill the chip.  Workgroup ids [0, n_sig) are signal jobs, the rest IR jobs.
-template <int LOG2M, bool QUAD = false>
+template <int LOG2M>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_forward_spectra_split(al_batch b, int n_sig) {
   __shared__ float2 s[FftGeom<LOG2M - 1, 16>::LDS_ELEMS];
   __shared__ float red[48];
   const int id = blockIdx.x;
   if (id < n_sig) {
-    signal_spectra_split_body<LOG2M, QUAD>(b, s, id % b.max_nj, id / b.max_nj);
+    signal_spectra_split_body<LOG2M>(b, s, id % b.max_nj, id / b.max_nj);
   } else {
     // Workgroup ids are dealt round-robin over the 8 XCDs; with the partition index as the plain remainder of the id an XCD would
     // only ever see partitions of one residue class (12 partitions per row: p mod 4 fixed per XCD), and the trimmed late
     // partitions of moving events (al_batch.emitter_parts) would be some XCDs' work only.  Rotating the index by the row gives every
     // XCD every partition: -2 % on cfg2's launch, -0.4 % on cfg3's (profiles/r04z_forward_id_mapping_ab.txt).
     const int q = id - n_sig, pc = b.n_partitions * b.n_capsules, row = q / b.n_partitions;
-    ir_spectra_split_body<LOG2M, QUAD>(b, s, red, (q + row) % b.n_partitions, row % b.n_capsules, q / pc);
+    ir_spectra_split_body<LOG2M>(b, s, red, (q + row) % b.n_partitions, row % b.n_capsules, q / pc);
   }
 }
 
 // ------------------------------------------------------------------ 5s. block synthesis, split layout
-template <int LOG2M, bool QUAD = false>
+template <int LOG2M>
 __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k_block_synthesis_split(al_batch b) {
   using G = FftGeom<LOG2M - 1, 16>;
-  using L = std::conditional_t<QUAD, QuadSlots<G::M>, PlainSlots>;
+  using L = PlainSlots;
   constexpr int M = G::M, T = G::T, E = G::E, B = 2 * M;
   constexpr HalfTurnFactors<G> hf{};
   __shared__ float2 s[G::LDS_ELEMS];
@@ -236,7 +235,6 @@ __global__ __launch_bounds__((FftGeom<LOG2M - 1, 16>::T), AL_SPLIT_WAVES) void k
   const int k = blockIdx.x, c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (k >= ev.n_blocks) return;
-  if ((b.flags & AL_FLAG_FUSED_STATIC) && ev.n_streams == 1) return;
   float *out = b.spatial + ev.out_off + (int64_t)c * ev.len;
   const int tbase = k * B;
   float asum = 0.f, amax = 0.f, bad = 0.f;

@@ -7,7 +7,7 @@
 
 #include "al_common.h"
 #include "al_fft.h"
-#include "al_fused.h"
+#include "al_synth_store.h"
 
 namespace al {
 
@@ -158,7 +158,6 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
   const int k0 = blockIdx.x * nb, c = blockIdx.y;
   const al_event ev = b.events[b.event0 + blockIdx.z];
   if (k0 >= ev.n_blocks) return;
-  if ((b.flags & AL_FLAG_FUSED_STATIC) && ev.n_streams == 1) return;  // k_mac_synthesis
   const int k1 = min(k0 + nb, ev.n_blocks);
   FftTwiddles<G> tw;
   load_fft_twiddles<G, 1>(tw, reinterpret_cast<const float2 *>(b.twiddle), tid0);
@@ -215,17 +214,12 @@ __global__ __launch_bounds__((FftGeom<LOG2M, E>::T), min_waves(E)) void k_block_
 
 }  // namespace al
 #include "al_split.h"
-#include "al_quad.h"
 #include "al_quad16.h"
 namespace al {
 
 // ------------------------------------------------------------------ launchers
 #define AL_DISPATCH_SPLIT(b, KERNEL, GRID, ...)                                                                          \
   do {                                                                                                                  \
-    if (((b)->flags & AL_FLAG_QUAD_SPECTRA) && (b)->log2_block == 13) {   /* quad layout: B = 8192 only */              \
-      hipLaunchKernelGGL((KERNEL<13, true>), GRID, dim3(FftGeom<12, 16>::T), 0, stream, __VA_ARGS__);                   \
-      break;                                                                                                            \
-    }                                                                                                                   \
     switch ((b)->log2_block) {                                                                                          \
       case 11: hipLaunchKernelGGL((KERNEL<11>), GRID, dim3(FftGeom<10, 16>::T), 0, stream, __VA_ARGS__); break;         \
       case 12: hipLaunchKernelGGL((KERNEL<12>), GRID, dim3(FftGeom<11, 16>::T), 0, stream, __VA_ARGS__); break;         \
@@ -310,24 +304,6 @@ hipError_t launch_signal_spectra(const al_batch *b, hipStream_t stream) {
     return hipGetLastError();
   }
   AL_DISPATCH_GEOM(b, k_signal_spectra, grid, *b);
-  return hipGetLastError();
-}
-
-hipError_t launch_mac_synthesis(const al_batch *b, hipStream_t stream) {
-  constexpr int KT = AL_FUSED_KT;
-  const int64_t pairs = (int64_t)b->n_capsules * b->n_events, n_ktiles = (b->max_blocks + KT - 1) / KT;
-  const int64_t n_wg = (pairs + 7) / 8 * 8 * n_ktiles;   // see the workgroup mapping in k_mac_synthesis
-  if (n_wg > 0x7fffffff) return hipErrorInvalidValue;
-  const dim3 grid((unsigned)n_wg);
-  const int P = b->n_partitions;
-  if (P <= 6) {
-    if (P == 6) hipLaunchKernelGGL((k_mac_synthesis<KT, 6, true>), grid, dim3(512), 0, stream, *b);
-    else hipLaunchKernelGGL((k_mac_synthesis<KT, 6, false>), grid, dim3(512), 0, stream, *b);
-  } else if (P % 12 == 0) {
-    hipLaunchKernelGGL((k_mac_synthesis<KT, 12, true>), grid, dim3(512), 0, stream, *b);
-  } else {
-    hipLaunchKernelGGL((k_mac_synthesis<KT, 12, false>), grid, dim3(512), 0, stream, *b);
-  }
   return hipGetLastError();
 }
 

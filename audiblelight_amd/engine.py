@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _hip, switches
-from .plan import SPARSE_MAX_PARTITIONS, BatchPlan, MixPlan
+from .plan import BatchPlan, MixPlan
 
 
 def _debug_flags() -> int:
@@ -478,16 +478,6 @@ class Renderer:
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
         sw = switches.current()      # parsed once per process (switches.py): nothing on this path reads the environment
         parts = plan.emitter_parts() if sw.trim_partitions else None
-        # EXPERIMENTAL, off by default (AL_FUSED_MOVING=1): sliding-window moving events through k_moving_fused (csrc/al_quad.h).
-        # The accumulate transforms the IR partitions itself, their spectra are never written (cfg3: 36 -> 17 GB per scene) --
-        # but one 512-thread workgroup per CU cannot overlap its load / transform / product phases, and it measures 8.8 ms
-        # against 6.9 ms per cfg3 scene (profiles/r04b_cfg3_fused_first_version_ab.txt).  Needs the split + quad layout (B = 8192).
-        fuse_moving = (sw.fused_moving and plan.log2_block == 13 and not sw.fused_static and sw.split is not False
-                       and 1 <= P <= SPARSE_MAX_PARTITIONS)
-        fused_parts = plan.fused_moving_parts(parts) if fuse_moving else None
-        fuse_moving = fused_parts is not None
-        if fuse_moving:
-            parts = fused_parts
         if parts is not None:        # al_batch.emitter_parts: IR partitions that cannot reach a kept block are not transformed
             tables.append(parts)
         tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]
@@ -497,7 +487,7 @@ class Renderer:
         bufs = dict(
             audio=audio_dev, ir=irs, events=tabs[0], streams=tabs[1], wtab=tabs[2], twiddle=self.twiddle(plan.log2_block),
             ir_energy=mem.empty(plan.hspec_blocks), emitter_gain=mem.empty(plan.n_emitters),
-            # one extra, all-zero block behind each spectra workspace: al_mac_synthesis reads out-of-range blocks from it
+            # one extra, all-zero block behind each spectra workspace: the LDS-DMA accumulate reads the rows past an odd partition count from it
             hspec=mem.empty((h_blocks + 1) * B * 2), xspec=mem.empty((x_blocks + 1) * B * 2),
             yspec=mem.empty(y_blocks * B * 2), spatial=mem.empty(plan.spatial_floats),
             partials=mem.empty(plan.n_partials * 4), event_stats=mem.empty(len(plan.events) * 4, np.float64),
@@ -528,7 +518,7 @@ class Renderer:
         for desc, chunk in zip(descs, chunks):
             desc.flags |= plan.batch_flags(chunk, lib=self.lib)
             if sw.forces_dispatch:
-                desc.flags = self._forced_dispatch(desc, plan, sw, fuse_moving)
+                desc.flags = self._forced_dispatch(desc, plan, sw)
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe
             pre, mode = tabs[3], tabs[4]
             for desc in descs:
@@ -536,27 +526,17 @@ class Renderer:
             bufs["_clip_tables"] = (pre, mode)
         return PreparedBatch(self, plan, bufs, descs, lanes)
 
-    def _forced_dispatch(self, desc, plan: BatchPlan, sw, fuse_moving: bool) -> int:
+    def _forced_dispatch(self, desc, plan: BatchPlan, sw) -> int:
         """al_batch.flags with the A/B switches applied on top of the library's policy (tests and measurements only)."""
         lb, P = plan.log2_block, plan.n_partitions
         layout = _hip.FLAG_SPLIT_SPECTRA | _hip.FLAG_QUAD_SPECTRA
         accumulate = _hip.FLAG_STATIC_MAC | _hip.FLAG_ONLY_STATIC
         flags = desc.flags & ~layout
-        quad16 = lb == 14 and not sw.fused_static and sw.quad16      # AL_QUAD16=0: the one- / two-transform kernels at B = 16384
-        want_split = sw.split if sw.split is not None else ((lb == 13 and not sw.fused_static) or quad16)
+        quad16 = lb == 14 and sw.quad16      # AL_QUAD16=0: the one- / two-transform kernels at B = 16384
+        want_split = sw.split if sw.split is not None else (lb == 13 or quad16)
         if want_split and lb >= 11:
-            flags |= _hip.FLAG_SPLIT_SPECTRA
-            if fuse_moving:
-                flags |= _hip.FLAG_QUAD_SPECTRA | _hip.FLAG_FUSED_MOVING | (_hip.FLAG_FUSED_NJ5 if plan.max_nj_sliding() <= 5 else 0)
-            elif (lb == 13 and sw.quad) or quad16:
-                flags |= _hip.FLAG_QUAD_SPECTRA
-        # EXPERIMENTAL (AL_FUSED=1): accumulate + synthesis of static events in one kernel (csrc/al_fused.h).  It removes the Y
-        # round trip (45 % of the HBM bytes) but is slower on MI355X as it stands (profiles/r02_fused.txt).
-        if sw.fused_static and not (want_split and lb >= 11):
-            desc.flags = flags
-            if self.lib.call("al_fused_supported", ct.byref(desc)):
-                flags |= _hip.FLAG_FUSED_STATIC
-        if not sw.static_mac or (sw.static_mac_max_p is not None and P > sw.static_mac_max_p) or (flags & _hip.FLAG_FUSED_STATIC):
+            flags |= _hip.FLAG_SPLIT_SPECTRA | (_hip.FLAG_QUAD_SPECTRA if quad16 else 0)
+        if not sw.static_mac or (sw.static_mac_max_p is not None and P > sw.static_mac_max_p):
             flags &= ~accumulate
         return flags
 
@@ -650,22 +630,8 @@ class PreparedBatch:
         return self.result()
 
     def stage_names(self, chunk: int = 0) -> Sequence[str]:
-        """The C-ABI calls one pass of a chunk makes, in order (bench.py times them one by one).  With
-        AL_FLAG_FUSED_STATIC the static events go through al_mac_synthesis; the unfused accumulate / synthesis are
-        launched only if the chunk has other events (moving: both; tiled dry clips: synthesis)."""
-        desc = self.descs[chunk]
-        if not (desc.flags & _hip.FLAG_FUSED_STATIC):
-            return self.STAGES
-        ev = self.plan.events[desc.event0: desc.event0 + desc.n_events]
-        moving, tiled = bool((ev["n_streams"] > 1).any()), bool((ev["n_streams"] == 0).any())
-        out = ["al_forward_spectra", "al_emitter_gains"]
-        if moving:
-            out.append("al_spectral_mac")
-        if bool((ev["n_streams"] == 1).any()):
-            out.append("al_mac_synthesis")
-        if moving or tiled:
-            out.append("al_block_synthesis")
-        return tuple(out + ["al_event_levels"])
+        """The C-ABI calls one pass of a chunk makes, in order (bench.py times them one by one)."""
+        return self.STAGES
 
     def run_stage(self, name: str, chunk: int = 0) -> None:
         self.renderer.lib.call(name, ct.byref(self.descs[chunk]), self.renderer.mem.stream())

@@ -136,34 +136,17 @@ class BatchPlan:
                                                       self.hop, self._win, self.fft_size, _lib(self._library)), _lib(self._library))
         return self._handle.ptr
 
-    def _parts(self, fused_moving: bool) -> Optional[np.ndarray]:
-        if not len(self.events) or self.n_emitters <= 0:
-            return None
-        out = np.zeros(self.n_emitters, dtype=np.int32)
-        have = _lib(self._library).call("al_plan_emitter_parts", self._c_plan(), 1 if fused_moving else 0, out.ctypes.data)
-        return out if have == 1 else None
-
     def emitter_parts(self) -> Optional[np.ndarray]:
         """al_batch.emitter_parts: per IR column, how many leading partitions can reach a block its event keeps (None: every
         partition of every IR).  pad_or_truncate_audio (synthesize.py:590) drops the convolution's tail from block n_blocks
         on, and partition p of an IR whose signal starts at block j_lo only feeds blocks >= j_lo + p.  Only the IRs of
         sliding-window moving events (al_event.reserved == 1: the one accumulate that honours it) get fewer than P; a
         column shared by several streams keeps the largest demand.  (csrc/al_plan.cpp: al_plan_emitter_parts.)"""
-        return self._parts(False)
-
-    def fused_moving_parts(self, base: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
-        """al_batch.emitter_parts for AL_FLAG_FUSED_MOVING: 0 ("energy only": the forward kernel takes the IR's energy for
-        normalize_irs and neither transforms nor stores it) for every IR column heard ONLY by sliding-window moving events
-        (al_event.reserved == 1) -- k_moving_fused transforms those partitions itself -- and the trimmed count (``base``:
-        None = no trimming, all P partitions) for the others.  None when the batch has no such event."""
-        if not len(self.events) or not (self.events["reserved"] == 1).any() or self.n_partitions < 1:
+        if not len(self.events) or self.n_emitters <= 0:
             return None
-        out = self._parts(True)
-        if out is None:
-            return None
-        if base is None:     # the caller switched the trimming off: full partition counts for the columns that are transformed
-            out = np.where(out == 0, 0, self.n_partitions).astype(np.int32)
-        return out
+        out = np.zeros(self.n_emitters, dtype=np.int32)
+        have = _lib(self._library).call("al_plan_emitter_parts", self._c_plan(), out.ctypes.data)
+        return out if have == 1 else None
 
     def max_nj_sliding(self) -> int:
         """Longest stream (in signal blocks) of the sliding-window moving events."""

@@ -23,9 +23,6 @@ def _flag(name: str):
 class Switches:
     split: Optional[bool] = None          # AL_SPLIT=0/1: force the one-transform / split-layout kernels (None: library policy)
     quad16: bool = True                   # AL_QUAD16=0: B = 16384 without the quad-tile kernels (split or one-transform instead)
-    quad: bool = False                    # AL_QUAD=1: the quad slot layout at B = 8192 without the fused moving kernel
-    fused_static: bool = False            # AL_FUSED=1: k_mac_synthesis for static events (experimental, slower)
-    fused_moving: bool = False            # AL_FUSED_MOVING=1: k_moving_fused for sliding-window moving events (experimental, slower)
     static_mac: bool = True               # AL_STATIC_MAC=0: one-emitter events through the tile accumulate
     static_mac_max_p: Optional[int] = None   # AL_STATIC_MAC_MAX_P: capsule-loop accumulate only up to that many partitions
     trim_partitions: bool = True          # AL_TRIM_PARTITIONS=0: transform IR partitions no kept block hears (al_batch.emitter_parts off)
@@ -47,7 +44,6 @@ class Switches:
         return cls(
             split=_flag("AL_SPLIT"),
             quad16=env("AL_QUAD16", "1") == "1",
-            quad=env("AL_QUAD", "0") == "1", fused_static=env("AL_FUSED", "0") == "1", fused_moving=env("AL_FUSED_MOVING", "0") == "1",
             static_mac=env("AL_STATIC_MAC", "1") == "1",
             static_mac_max_p=int(env("AL_STATIC_MAC_MAX_P")) if env("AL_STATIC_MAC_MAX_P") else None,
             trim_partitions=env("AL_TRIM_PARTITIONS", "1") == "1",
@@ -66,8 +62,7 @@ class Switches:
     @property
     def forces_dispatch(self) -> bool:
         """True when a switch overrides the kernel choice of ``al_plan_batch_flags``."""
-        return (self.split is not None or not self.quad16 or not self.static_mac or self.static_mac_max_p is not None
-                or self.quad or self.fused_static or self.fused_moving)
+        return self.split is not None or not self.quad16 or not self.static_mac or self.static_mac_max_p is not None
 
 
 _current: Optional[Switches] = None

@@ -30,7 +30,10 @@ extern "C" {
  * struct_size + abi_version at the head of both, so a descriptor built against another header is refused, not misread;
  * version 4 appends al_batch.emitter_parts; version 5 adds the host-side planner (al_plan_*, al_workspace_bytes,
  * al_plan_mixdown) and the AL_FLAG_QUAD_SPECTRA / AL_FLAG_FUSED_MOVING path: no struct changed; version 6 adds
- * al_plan_batch_flags -- the dispatch policy (layout + accumulate flags per chunk) moves from the hosts into the library). */
+ * al_plan_batch_flags -- the dispatch policy (layout + accumulate flags per chunk) moves from the hosts into the library --
+ * and al_scale_rows_f64; the opt-in fused kernels of versions 2-5 (AL_FLAG_FUSED_STATIC / _FUSED_MOVING / _FUSED_NJ5,
+ * al_mac_synthesis, al_fused_supported, al_moving_fused_supported, the quad layout at B = 8192, the fused_moving argument of
+ * al_plan_emitter_parts) are gone: measured 20-35 % slower than the stored-spectra path, profiles/r05c_fused_ab.txt). */
 #define AL_ABI_VERSION 6
 
 #define AL_OK 0
@@ -42,30 +45,17 @@ extern "C" {
 #define AL_FLAG_NO_IR_NORM 1 /* IRs are already normalised: emitter_gain := 1 (time_invariant_convolution,
                                  time_variant_convolution called directly, synthesize.py:71,277) */
 
-#define AL_FLAG_FUSED_STATIC 2 /* static events (one emitter) go through al_mac_synthesis (accumulate + block synthesis in one
-                                  kernel, output spectra never written); al_spectral_mac / al_block_synthesis then skip
-                                  them.  Needs al_fused_supported(b) != 0. */
 #define AL_FLAG_SPLIT_SPECTRA 32 /* spectra in the split layout of csrc/al_split.h (even bins | odd bins, every window transformed
                                     as two half-size FFTs); all of al_ir_spectra / al_signal_spectra / al_block_synthesis must
-                                    see the same setting; the accumulate does not care.  B >= 2048; excludes AL_FLAG_FUSED_STATIC */
+                                    see the same setting; the accumulate does not care.  B >= 2048 */
 #define AL_FLAG_STATIC_MAC 64   /* al_spectral_mac: static (one-emitter) events of batches with at most 21 partitions through k_spectral_mac_static (one workgroup per
                                    (event, k-tile, bin tile) looping over the capsules); the tile kernels skip them */
 #define AL_FLAG_ONLY_STATIC 128 /* with AL_FLAG_STATIC_MAC: the batch has no multi-emitter event, so the other accumulate
                                    kernels are not launched at all (the host knows the event table, the library does not) */
-#define AL_FLAG_QUAD_SPECTRA 256 /* with AL_FLAG_SPLIT_SPECTRA at B = 8192: every half of a spectrum stored as two tiles of B/4 slots,
-                                    each a plain B/4-point transform of the folded window (csrc/al_quad.h, QuadSlots in csrc/al_fft.h):
-                                    what lets a workgroup make ITS slice of an IR partition's spectrum from the raw samples.
-                                    With AL_FLAG_SPLIT_SPECTRA at B = 16384: the four-tile layout of csrc/al_quad16.h (every window as
-                                    four 4096-point transforms) -- set both there: the one-transform kernels are 15-20 % slower
-                                    per scene at that block size.  The planner (al_plan_create) picks B = 16384 by itself only for
-                                    big batches of static events with 17..24 partitions of 8192 */
-#define AL_FLAG_FUSED_MOVING 512 /* with AL_FLAG_QUAD_SPECTRA: sliding-window moving events (al_event.reserved == 1) go through
-                                    k_moving_fused, which transforms the IR partitions itself: their spectra are never written.
-                                    The caller sets emitter_parts[n] = 0 for the IR columns of those events (the forward kernel
-                                    then only takes their energies for normalize_irs).  Needs al_moving_fused_supported(b) != 0 */
-#define AL_FLAG_FUSED_NJ5 1024   /* with AL_FLAG_FUSED_MOVING: every stream of every sliding-window event has at most 5 signal blocks
-                                    (al_plan_info.max_nj_sliding; the host knows the stream table, the library does not):
-                                    k_moving_fused<5,8> (8 partitions per pass) instead of <6,4> */
+#define AL_FLAG_QUAD_SPECTRA 256 /* with AL_FLAG_SPLIT_SPECTRA at B = 16384: the four-tile layout of csrc/al_quad16.h (every window as
+                                    four 4096-point transforms) -- set both there: the one- / two-transform kernels are 15-20 %
+                                    slower per scene at that block size.  Ignored at other block sizes.  al_plan_batch_flags sets
+                                    the layout flags for the plan's block size */
 #define AL_FLAG_NARROW_FFT 4 /* A/B switch: 16 complex values per thread at every block size (default: 32 from
                                B = 8192 up, see csrc/al_fft.h) */
 #define AL_FLAG_SYNTH_RUN(n) (((n) & 0xff) << 16) /* al_block_synthesis: n consecutive blocks per workgroup (0 = 1) */
@@ -160,8 +150,8 @@ typedef struct {
   const float *clip_scale; /* optional (NULL = 1): per event scalar applied to the clip on top of al_stream.gain; written on
                               the device by al_clip_scales (peak normalisation + folded Gain/Invert, event.py:529-536), so
                               the clip's peak never travels to the host.  Indexed globally like event_scale. */
-  int32_t xspec_zero_block; /* index of an all-zero block inside xspec / hspec (-1: none).  al_mac_synthesis reads */
-  int32_t hspec_zero_block; /* out-of-range signal blocks / partitions from them instead of masking per lane. */
+  int32_t xspec_zero_block; /* index of an all-zero block inside xspec / hspec (-1: none): the LDS-DMA accumulate reads the rows past */
+  int32_t hspec_zero_block; /* an odd partition count from it instead of masking per lane (13..21 partitions need hspec_zero_block). */
   const int32_t *emitter_parts; /* optional (NULL = n_partitions everywhere), indexed globally by IR column: how many leading
                                    partitions of that IR can reach a block some event keeps.  pad_or_truncate_audio
                                    (synthesize.py:590) drops everything from block n_blocks on, and partition p of an IR whose
@@ -221,17 +211,10 @@ int al_spectral_mac(const al_batch *b, al_stream_t stream);    /* A2/A7 frequenc
  * D = 1: k_spectral_mac_static<12,P,1> (clips of at most 12 blocks), 2: <12,P,2> (13..24 blocks), 3: the partition spectra
  * staged through LDS by registers, k_spectral_mac_static_lds<12,P> (more than 24 blocks) or <12,ceil(P/2),2> (13..16
  * partitions without hspec_zero_block), 4: staged by LDS-DMA, k_spectral_mac_static_glds (13..21 partitions as two or three
- * units per capsule, any clip length; needs hspec_zero_block >= 0); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events, 10000 + 100*NJW + PTW for
- * the IR-transform-fused one (AL_FLAG_FUSED_MOVING: k_moving_fused<NJW,PTW>, PTW partitions per pass: 10508 / 10604), 0 = not launched. */
+ * units per capsule, any clip length; needs hspec_zero_block >= 0); *moving_code = 100*NJW + PT of the sliding-window kernel for moving events,
+ * 0 = not launched. */
 int al_spectral_mac_variant(const al_batch *b, int32_t *static_code, int32_t *moving_code);
 int al_block_synthesis(const al_batch *b, al_stream_t stream); /* inverse FFT, A3 truncate/pad, A4/A5 statistics */
-/* A2 + A3 + statistics for static events in ONE kernel (csrc/al_fused.h): output spectra stay in registers.
- * al_fused_supported: 1 if this batch can use it (B = 8192, both zero blocks given, static events present). */
-int al_fused_supported(const al_batch *b);
-/* 1 if the batch can run with AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_MOVING: B = 8192, at most AL_SPARSE_MAX_PARTITIONS partitions,
- * split + quad layout flags set */
-int al_moving_fused_supported(const al_batch *b);
-int al_mac_synthesis(const al_batch *b, al_stream_t stream);
 int al_event_levels(const al_batch *b, al_stream_t stream);    /* A9 composite level law -> event_scale */
 /* The two halves of al_event_levels, for a scene whose capsules are sharded over several GPUs: every rank reduces
  * its own capsules into event_stats[e] = {sum|x|, max|x|, non-finite count, -}, the ranks all-reduce those E triples
@@ -395,7 +378,7 @@ typedef struct {
   int32_t log2_block, n_capsules, ir_len, n_events, n_streams, n_emitters, n_partitions, hop, fft_size;
   int32_t max_blocks;       /* al_batch.max_blocks of the whole batch */
   int32_t max_nj;           /* al_batch.max_nj */
-  int32_t max_nj_sliding;   /* longest stream of the sliding-window events (<= 5: AL_FLAG_FUSED_NJ5 may be set) */
+  int32_t max_nj_sliding;   /* longest stream of the sliding-window events */
   int32_t xspec_blocks, yspec_blocks, n_partials;   /* blocks of B complex / entries of 4 floats */
   int32_t reserved;
   int64_t hspec_blocks;     /* n_emitters * n_capsules * n_partitions */
@@ -444,7 +427,7 @@ int al_plan_chunk(const al_plan *plan, int32_t event0, int32_t n_events, al_chun
 /* bytes of the spectra workspaces + statistics of the whole batch as ONE chunk (hspec, xspec, yspec, ir_energy, emitter_gain, partials) */
 int64_t al_workspace_bytes(const al_plan *plan);
 /* al_batch.emitter_parts: returns 1 and fills out[n_emitters] if the batch needs the table, 0 if every IR needs all partitions */
-int al_plan_emitter_parts(const al_plan *plan, int32_t fused_moving, int32_t *out);
+int al_plan_emitter_parts(const al_plan *plan, int32_t *out);
 /* Dispatch policy: al_batch.flags for a chunk of the plan (chunk == NULL: the whole plan as one batch) -- the layout flags for
  * the plan's block size (AL_FLAG_SPLIT_SPECTRA at 8192, + AL_FLAG_QUAD_SPECTRA at 16384) and the accumulate flags for the chunk's
  * event mix (AL_FLAG_STATIC_MAC when it has one-emitter events and at most AL_STATIC_MAC_MAX_PARTITIONS partitions, +

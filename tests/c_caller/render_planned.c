@@ -10,7 +10,7 @@
  *
  *   render_planned <in.bin> <out.bin>
  *   in.bin : int32 C, E, N (IR columns), Lir, log2_block (0 = library's choice), chunk_events (0 = one batch), has_ambience,
- *                  fused (1 = AL_FLAG_FUSED_MOVING where the library supports the batch)
+ *                  reserved (0)
  *            float32 ref_db, sample_rate, duration, ambience_ref_db
  *            E x { int32 n_samples, n_emitters, emitter0, is_moving; float32 snr, scene_start }
  *            float32 clips (concatenated), float32 irs[C][N][Lir], float32 noise[C][T] if has_ambience (T = round(duration * sr))
@@ -59,7 +59,7 @@ int main(int argc, char **argv) {
   int32_t hdr[8];
   float fl[4];
   if (fread(hdr, 4, 8, f) != 8 || fread(fl, 4, 4, f) != 4) return 1;
-  const int C = hdr[0], E = hdr[1], N = hdr[2], Lir = hdr[3], want_lb = hdr[4], chunk_events = hdr[5], has_amb = hdr[6], want_fused = hdr[7];
+  const int C = hdr[0], E = hdr[1], N = hdr[2], Lir = hdr[3], want_lb = hdr[4], chunk_events = hdr[5], has_amb = hdr[6];
   const float ref_db = fl[0], sr = fl[1], duration = fl[2], amb_ref_db = fl[3];
   al_event_spec *specs = calloc(E, sizeof *specs);
   double *starts = malloc(8 * E), *ends = malloc(8 * E);
@@ -138,16 +138,11 @@ int main(int argc, char **argv) {
   HIP_OK(hipMemsetAsync((char *)b.xspec + (size_t)x_max * blk, 0, blk, stream));
   b.hspec_zero_block = (int32_t)h_max, b.xspec_zero_block = (int32_t)x_max;
   /* the dispatch policy is the library's (al_plan_batch_flags): layout flags for the block size, accumulate flags per chunk's
-   * event mix -- this host decides nothing; `extra` is only the opt-in experimental moving kernel this test can ask for */
-  int32_t whole = 0, extra = 0;
+   * event mix -- this host decides nothing */
+  int32_t whole = 0;
   AL_CALL(al_plan_batch_flags(plan, NULL, &whole));
-  int fused = 0;
-  if (want_fused && info.log2_block == 13 && info.max_nj_sliding >= 1 && info.max_nj_sliding <= 5) {
-    b.flags = whole | AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5;
-    if (al_moving_fused_supported(&b)) fused = 1, extra = AL_FLAG_QUAD_SPECTRA | AL_FLAG_FUSED_NJ5 | AL_FLAG_FUSED_MOVING;
-  }
   int32_t *parts = malloc(4 * (size_t)(info.n_emitters + 1));
-  const int have_parts = al_plan_emitter_parts(plan, fused, parts);
+  const int have_parts = al_plan_emitter_parts(plan, parts);
   if (have_parts < 0) return 3;
   if (have_parts) b.emitter_parts = dev_copy(parts, 4 * (size_t)info.n_emitters, stream);
   AL_CALL(al_twiddle_init((float *)b.twiddle, info.log2_block, stream));
@@ -159,7 +154,7 @@ int main(int argc, char **argv) {
     b.emitter0 = ch.emitter0, b.n_emitters = ch.n_emitters, b.xspec_block0 = ch.xspec_block0, b.yspec_block0 = ch.yspec_block0;
     int32_t policy = 0;
     AL_CALL(al_plan_batch_flags(plan, &ch, &policy));
-    b.max_blocks = ch.max_blocks, b.max_nj = ch.max_nj, b.flags = policy | extra;
+    b.max_blocks = ch.max_blocks, b.max_nj = ch.max_nj, b.flags = policy;
     AL_CALL(al_render_batch(&b, stream));
   }
 
@@ -218,10 +213,10 @@ int main(int argc, char **argv) {
   al_chunk all;
   AL_CALL(al_plan_chunk(plan, 0, E, &all));
   b.event0 = 0, b.n_events = E, b.stream0 = all.stream0, b.n_streams = all.n_streams, b.emitter0 = all.emitter0, b.n_emitters = all.n_emitters;
-  b.max_blocks = all.max_blocks, b.max_nj = all.max_nj, b.flags = whole | extra;
+  b.max_blocks = all.max_blocks, b.max_nj = all.max_nj, b.flags = whole;
   AL_CALL(al_spectral_mac_variant(&b, &sc, &mc));
-  printf("rendered %d events x %d capsules in %d chunk(s), B = %d, P = %d, fused_moving = %d, moving_code = %d, static_code = %d, flags = %d, skipped = %d\n",
-         E, C, n_chunks, B, P, fused, mc, sc, whole | extra, mt.n_skipped);
+  printf("rendered %d events x %d capsules in %d chunk(s), B = %d, P = %d, moving_code = %d, static_code = %d, flags = %d, skipped = %d\n",
+         E, C, n_chunks, B, P, mc, sc, whole, mt.n_skipped);
   al_mix_plan_destroy(mp);
   al_plan_destroy(plan);
   return 0;

@@ -82,26 +82,7 @@ syn.set_renderer(None)
 print("asan run ok: round-3 kernels")
 
 # round 4: the planner behind the C ABI ran for every batch above (al_plan_create / al_plan_chunk / al_plan_emitter_parts /
-# al_plan_mixdown from the sanitized library); here the quad spectrum layout and k_moving_fused (csrc/al_quad.h) at B = 8192:
-# two passes over 10 partitions with a ragged last one, streams of 5 and of 6 blocks, tile 0's real-FFT unpacking, and a static
-# event beside it in the quad layout
-setenv("AL_SPLIT", "1")
-setenv("AL_FUSED_MOVING", "1")
-B = 8192
-for n_irs, k_mult in ((6, 7.3), (4, 6.1)):
-    La, Lir = int(k_mult * B), int(9.3 * B)
-    clips = [rng.standard_normal(La).astype(np.float32), rng.standard_normal(2 * B + 5).astype(np.float32)]
-    irs = (rng.standard_normal((1, n_irs + 1, Lir)) * np.exp(-np.arange(Lir) / (Lir / 5.0))).astype(np.float32)
-    specs = [planning.EventSpec(n_samples=La, n_emitters=n_irs, snr=10.0, emitter0=0, is_moving=True, duration=La / 48000),
-             planning.EventSpec(n_samples=len(clips[1]), n_emitters=1, snr=12.0, emitter0=n_irs)]
-    pl = planning.plan_batch(specs, 1, Lir, 48000, log2_block=13)
-    batch = r.prepare(pl, clips, irs)
-    r.lib.call("al_spectral_mac_variant", ct.byref(batch.descs[0]), ct.byref(s_code), ct.byref(m_code))
-    assert m_code.value >= 10000, m_code.value
-    res = batch.run()
-    res.check_finite()
-    print("asan run ok: fused moving accumulate, code", m_code.value, float(np.abs(res.spatial_audio(0)).sum()))
-setenv("AL_FUSED_MOVING", None)
+# al_plan_mixdown / al_plan_batch_flags from the sanitized library)
 # the quad-tile transforms at B = 16384 (csrc/al_quad16.h): a run of five IR partitions with a ragged last one (the prefetch
 # hand-over), interior and edge signal windows, the rolled general signal path (moving event), the four-tile inverse
 B = 16384

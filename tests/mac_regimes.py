@@ -51,7 +51,6 @@ GLDS_CASES += [("glds_cfg2_shape", 3121204, 23.44, 11.72, 5, 2), ("glds_ragged_s
 # k_spectral_mac_static_lds<12,{7,8},2>: 13..16 partitions for a caller that gave no all-zero block (hspec_zero_block = -1)
 NO_ZERO_BLOCK_CASES = [(f"no_zero_block_P{P}", 3120000 + 100 * P + 3, 20.6, P - 0.37, 2, 1) for P in (13, 14, 15, 16)]
 MOVING_CODES = [612, 624]       # asserted by test_moving_regimes / test_cfg3_regime_all_rows
-FUSED_MOVING_CODES = [10508, 10604]   # k_moving_fused<5,8> / <6,4> (csrc/al_quad.h; opt-in with AL_FUSED_MOVING=1 at B = 8192)
 # codes the GPU tests assert beyond the tables above: cfg4's <12,6,2>, cfg5's tile kernel with two full partition tiles
 EXTRA_STATIC_CODES = [3120602, 1121202]
 
@@ -60,9 +59,6 @@ def codes_of_kernel_symbol(sym: str):
     """Demangled kernel name (``nm -C``) -> the al_spectral_mac_variant codes under which it runs, as (kind, code) pairs."""
     import re
 
-    f = re.search(r"k_moving_fused<([0-9]+), ([0-9]+)>", sym)
-    if f:
-        return [("moving", 10000 + 100 * int(f.group(1)) + int(f.group(2)))]
     m = re.search(r"k_spectral_mac(_static_lds|_static_glds|_static|_moving)?<([0-9, a-z]+)>", sym)
     if not m:
         return []
@@ -90,7 +86,7 @@ def asserted_codes():
     """Every (kind, code) some -m gpu test asserts through al_spectral_mac_variant."""
     out = {("static", c[1]) for c in STATIC_CASES} | {("static", c[1]) for c in STATIC_LOOP_CASES} | {("static", c[1]) for c in GLDS_CASES}
     out |= {("static", c[1]) for c in NO_ZERO_BLOCK_CASES}
-    out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES + FUSED_MOVING_CODES}
+    out |= {("static", c) for c in EXTRA_STATIC_CODES} | {("moving", c) for c in MOVING_CODES}
     return out
 
 
@@ -115,16 +111,10 @@ def is_split(batch, chunk=0):
     return bool(batch.descs[chunk].flags & _hip.FLAG_SPLIT_SPECTRA)
 
 
-def is_fused(batch, chunk=0):
-    from audiblelight_amd import _hip
-
-    return bool(batch.descs[chunk].flags & _hip.FLAG_FUSED_STATIC)
-
-
-def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_fused=None, expect_split=None,
-                    zero_block=True, expect_quad=None):
-    """``expect_fused``: None = whatever the library picks (B = 8192: al_mac_synthesis, csrc/al_fused.h), True / False =
-    assert it (callers force the unfused kernels with AL_FUSED=0 so that their dispatch branches stay pinned too)."""
+def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0, expect_split=None, zero_block=True,
+                    expect_quad=None):
+    """A batch of E static events of about k_mult blocks against IRs of about p_mult partitions: the accumulate instantiation the
+    library reports must be ``code``, the layout flags what the caller expects, every row what the oracle renders."""
     B = 1 << log2_block
     rng = np.random.default_rng(100 * log2_block + seed)
     La, Lir = int(round(k_mult * B)), int(round(p_mult * B))
@@ -148,10 +138,6 @@ def run_static_case(renderer, log2_block, code, k_mult, p_mult, C=3, E=2, seed=0
     if expect_quad is not None:
         from audiblelight_amd import _hip
         assert bool(batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA) == expect_quad
-    if expect_fused is not None:
-        assert is_fused(batch) == expect_fused
-        assert ("al_mac_synthesis" in batch.stage_names()) == expect_fused
-        assert ("al_spectral_mac" in batch.stage_names()) == (not expect_fused)
     res = batch.run()
     res.check_finite()
     for e in range(E):
@@ -180,18 +166,12 @@ def run_moving_case(renderer, log2_block, p_mult, n_irs, k_mult, expect_moving, 
     batch = renderer.prepare(pl, clips, mic_ir)
     _, moving = mac_codes(renderer, batch)
     assert moving == expect_moving, moving
-    fused = expect_moving >= 10000      # k_moving_fused (csrc/al_quad.h): the IR spectra are never written at all
     if expect_moving:
         assert all(int(r) == 1 for r in pl.events["reserved"]), "planner did not flag the events for the sliding window"
         # al_batch.emitter_parts: partitions that only reach blocks past the clip's end are neither transformed nor read.  The
         # spectra workspace is poisoned first, so a read of a block that was not written would turn the event into NaNs.
         parts = pl.emitter_parts()
-        assert fused or (parts is not None and 0 <= parts.min() < pl.n_partitions and parts.max() <= pl.n_partitions)
-        if fused:
-            parts = pl.fused_moving_parts(parts)
-            assert (parts == 0).all()
-            from audiblelight_amd import _hip
-            assert batch.descs[0].flags & _hip.FLAG_QUAD_SPECTRA and batch.descs[0].flags & _hip.FLAG_FUSED_MOVING
+        assert parts is not None and 0 <= parts.min() < pl.n_partitions and parts.max() <= pl.n_partitions
         assert batch.descs[0].emitter_parts, "the planner's table did not reach the descriptor"
         n_real = pl.hspec_blocks * B * 2
         batch.bufs["hspec"][:n_real] = float("nan")

@@ -116,24 +116,6 @@ class BatchPlan:
         need[unused] = P
         return need if (need < P).any() else None
 
-    def fused_moving_parts(self, base: Optional[np.ndarray] = None) -> Optional[np.ndarray]:
-        """al_batch.emitter_parts for AL_FLAG_FUSED_MOVING: 0 ("energy only": the forward kernel takes the IR's energy for
-        normalize_irs and neither transforms nor stores it) for every IR column heard ONLY by sliding-window moving events
-        (al_event.reserved == 1) -- k_moving_fused transforms those partitions itself -- and ``base`` (default: all P
-        partitions) for the others.  None when the batch has no such event."""
-        if not len(self.events) or not len(self.streams) or not (self.events["reserved"] == 1).any() or self.n_partitions < 1:
-            return None
-        st, ev = self.streams, self.events
-        real = (ev["n_streams"][st["event"]] > 0) & (st["emitter"] >= 0) & (st["emitter"] < self.n_emitters)
-        out = np.full(self.n_emitters, self.n_partitions, dtype=np.int32) if base is None else np.array(base, dtype=np.int32)
-        fused = np.zeros(self.n_emitters, dtype=bool)
-        other = np.zeros(self.n_emitters, dtype=bool)
-        sliding = ev["reserved"][st["event"]] == 1
-        fused[st["emitter"][real & sliding]] = True
-        other[st["emitter"][real & ~sliding]] = True
-        out[fused & ~other] = 0
-        return out
-
     def max_nj_sliding(self) -> int:
         """Longest stream (in signal blocks) of the sliding-window moving events."""
         if not len(self.streams):

@@ -53,16 +53,14 @@ def test_c_host_renders_what_the_oracle_renders(tmp_path, C, E, La, Lir, log2_bl
 PLANNED = os.path.join(os.path.dirname(os.path.abspath(__file__)), "c_caller", "_build", "render_planned")
 
 
-@pytest.mark.parametrize("log2_block,chunk_events,fused,lir,expect_code", [(10, 0, 0, 2600, 612), (10, 2, 0, 2600, 612),
-                                                                              (13, 0, 1, 30_001, 10508), (13, 3, 1, 30_001, 10508),
-                                                                              (13, 0, 0, 30_001, 612), (14, 2, 0, 60_001, 612)],
-                         ids=["B1024_one_batch", "B1024_chunks_of_2", "B8192_fused_moving", "B8192_fused_moving_chunks_of_3", "B8192_stored_spectra",
-                              "B16384_quad_tiles_chunks_of_2"])
-def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fused, lir, expect_code):
+@pytest.mark.parametrize("log2_block,chunk_events,lir,expect_code", [(10, 0, 2600, 612), (10, 2, 2600, 612), (13, 0, 30_001, 612),
+                                                                        (13, 3, 30_001, 612), (14, 2, 60_001, 612)],
+                         ids=["B1024_one_batch", "B1024_chunks_of_2", "B8192_one_batch", "B8192_chunks_of_3", "B16384_quad_tiles_chunks_of_2"])
+def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, lir, expect_code):
     """tests/c_caller/render_planned.c: static + moving + tiled events, an ambience and a chunked batch from a C host that
     takes EVERY table from the library's planner (al_plan_create / al_plan_chunk / al_plan_emitter_parts / al_plan_mixdown);
-    every row of every event and of the scene against the oracle.  At B = 8192 the moving events go through k_moving_fused when
-    asked to; at B = 16384 the host sets the quad-tile layout flags (csrc/al_quad16.h)."""
+    every row of every event and of the scene against the oracle.  The layout and accumulate flags come from the library too
+    (al_plan_batch_flags: split at B = 8192, quad tiles at 16384)."""
     if not os.path.exists(PLANNED):
         import __graft_entry__
 
@@ -85,7 +83,7 @@ def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fus
     noise = rng.standard_normal((C, T)).astype(np.float32)
     src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
     with open(src, "wb") as f:
-        np.array([C, len(events), N, lir, log2_block, chunk_events, 1, fused], dtype=np.int32).tofile(f)
+        np.array([C, len(events), N, lir, log2_block, chunk_events, 1, 0], dtype=np.int32).tofile(f)
         np.array([ref_db, sr, duration, amb_db], dtype=np.float32).tofile(f)
         for ev in events:
             np.array([ev["n"], ev["ne"], ev["e0"], int(ev["mv"])], dtype=np.int32).tofile(f)
@@ -97,7 +95,7 @@ def test_c_host_with_the_library_planner(tmp_path, log2_block, chunk_events, fus
     run = subprocess.run([PLANNED, str(src), str(dst)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stderr + run.stdout
     n_chunks = 1 if chunk_events == 0 else -(-len(events) // chunk_events)
-    assert f"in {n_chunks} chunk(s)" in run.stdout and f"fused_moving = {fused}" in run.stdout and f"moving_code = {expect_code}" in run.stdout, run.stdout
+    assert f"in {n_chunks} chunk(s)" in run.stdout and f"moving_code = {expect_code}" in run.stdout, run.stdout
     out = np.fromfile(dst, dtype=np.float32)
     E = len(events)
     scale, at = out[:E], E

@@ -11,7 +11,7 @@ import pytest
 from scipy.signal import fftconvolve
 
 from oracle import synth_oracle as orc
-from tests.conftest import assert_parity, rel_rms, set_switch
+from tests.conftest import assert_parity, rel_rms
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
@@ -77,14 +77,12 @@ def _cfg3_scene():
     return _CFG3["scene"]
 
 
-@pytest.mark.parametrize("fused", ["0", "1"], ids=["stored_spectra", "fused_moving_kernel"])
-def test_cfg3_full_size_moving_sources(gpu, monkeypatch, fused):
-    """BASELINE configs[2]: 16 moving events x 32 waypoint IRs, 32 capsules, 2 s RIRs, 7.75 s clips @ 48 kHz (6.3 GB of IRs);
-    through the default path over stored IR spectra and through k_moving_fused (AL_FUSED_MOVING=1)."""
+def test_cfg3_full_size_moving_sources(gpu):
+    """BASELINE configs[2]: 16 moving events x 32 waypoint IRs, 32 capsules, 2 s RIRs, 7.75 s clips @ 48 kHz (6.3 GB of IRs)
+    through the default dispatch (sliding-window accumulate over stored IR spectra)."""
     from audiblelight_amd import plan as planning
     from tests import mac_regimes as mr
 
-    set_switch(monkeypatch, "AL_FUSED_MOVING", fused)
     sc = _cfg3_scene()
     assert sc.irs.shape == (32, 16 * 32, 96000) and len(sc.clips) == 16 and len(sc.clips[0]) == 372000
     pl = planning.plan_batch(sc.specs, sc.n_capsules, sc.ir_len, sc.sr)
@@ -92,7 +90,7 @@ def test_cfg3_full_size_moving_sources(gpu, monkeypatch, fused):
     assert all(int(r) == 1 for r in pl.events["reserved"])
     batch = gpu.prepare(pl, sc.clips, sc.irs)
     moving_code = mr.mac_codes(gpu, batch)[1]
-    assert moving_code == (10508 if fused == "1" else 612), moving_code
+    assert moving_code == 612, moving_code
     res = batch.run()
     scales = check_level_invariant(sc, res)
     gains = np.asarray(gpu.mem.download(res.emitter_gain))[: 16 * 32].astype(np.float64)

@@ -8,6 +8,8 @@ import pytest
 
 from tests.conftest import set_switch
 
+from tests.conftest import set_switch
+
 from tests import mac_regimes as mr
 
 pytestmark = pytest.mark.gpu
@@ -28,8 +30,7 @@ def test_static_regimes(gpu, log2_block, name, code, k_mult, p_mult, monkeypatch
     """The tile kernels (k_spectral_mac + k_block_synthesis): AL_STATIC_MAC=0 keeps their dispatch branches reachable for
     static events (they are the default for more than 12 partitions and for multi-emitter events)."""
     set_switch(monkeypatch, "AL_STATIC_MAC", "0")
-    set_switch(monkeypatch, "AL_FUSED", None)
-    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_fused=False, expect_split=(log2_block >= 13))   # 14: csrc/al_quad16.h
+    mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, expect_split=(log2_block >= 13))   # 14: csrc/al_quad16.h
 
 
 @pytest.mark.parametrize("log2_block", [10, 13])
@@ -39,7 +40,6 @@ def test_static_capsule_loop_kernel(gpu, monkeypatch, log2_block, name, code, k_
     instantiation -- partition counts 1..21 x {one k-tile, two k-tiles, more than 24 blocks} -- at B = 8192 and B = 1024, ragged tiles,
     the capsule-range split of small batches; every row against the oracle, the instantiation asserted."""
     set_switch(monkeypatch, "AL_STATIC_MAC", None)
-    set_switch(monkeypatch, "AL_FUSED", None)
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
 
 
@@ -50,7 +50,6 @@ def test_static_capsule_loop_glds_kernel(gpu, monkeypatch, log2_block, name, cod
     where it is an A/B switch (13..24 partitions take it by default: test_static_capsule_loop_kernel): every partition count
     1..12, second k-tile full / ragged / idle, one and several workgroups per (event, bin tile); every row against the oracle."""
     set_switch(monkeypatch, "AL_STATIC_MAC", None)
-    set_switch(monkeypatch, "AL_FUSED", None)
     set_switch(monkeypatch, "AL_EXTRA_FLAGS", str(1 << 14))
     mr.run_static_case(gpu, log2_block, code, k_mult, p_mult, C=C, E=E)
 
@@ -64,65 +63,12 @@ def test_static_capsule_loop_without_zero_block(gpu, monkeypatch, name, code, k_
     mr.run_static_case(gpu, 13, code, k_mult, p_mult, C=C, E=E, zero_block=False)
 
 
-@pytest.mark.parametrize("name,code,k_mult,p_mult", mr.STATIC_CASES, ids=[c[0] for c in mr.STATIC_CASES])
-def test_fused_static_regimes(gpu, name, code, k_mult, p_mult, monkeypatch):
-    """k_mac_synthesis (B = 8192, opt-in with AL_FUSED=1: experimental, see profiles/r02_fused.txt): k-tiles of 4 blocks
-    with ragged last tiles, one and two partition tiles (PT = 6 / 12, full and ragged instantiations), clips shorter and
-    longer than the IR; every row against the oracle."""
-    set_switch(monkeypatch, "AL_FUSED", "1")
-    mr.run_static_case(gpu, 13, code, k_mult, p_mult, expect_fused=True, expect_split=False)
-
-
-def test_fused_next_to_moving_and_tiled_events(gpu, monkeypatch):
-    """One batch with a static, a moving and a zero-emitter event at B = 8192: the fused kernel takes the static one,
-    the sliding-window accumulate + k_block_synthesis the moving one, k_block_synthesis the tiled one."""
-    import numpy as np
-
-    from audiblelight_amd import plan as planning
-    from oracle import synth_oracle as orc
-
-    set_switch(monkeypatch, "AL_FUSED", "1")
-    rng = np.random.default_rng(31)
-    sr, C, L, B = 48000, 3, 5 * 8192 + 100, 8192
-    specs, clips, irs, col = [], [], [], 0
-    for n_audio, n_emit in ((9 * B + 11, 1), (14 * B, 10), (3 * B + 5, 0), (2 * B - 3, 1)):
-        a = rng.standard_normal(n_audio).astype(np.float32)
-        clips.append(a / np.abs(a).max())
-        irs.append((rng.standard_normal((C, n_emit, L)) * np.exp(-np.arange(L) / (L / 5.0))).astype(np.float32))
-        specs.append(planning.EventSpec(n_samples=n_audio, n_emitters=n_emit, snr=float(rng.uniform(5, 30)), emitter0=col,
-                                        is_moving=n_emit > 1, duration=n_audio / sr))
-        col += n_emit
-    pl = planning.plan_batch(specs, C, L, sr, log2_block=13)
-    batch = gpu.prepare(pl, clips, np.concatenate(irs, axis=1))
-    assert mr.is_fused(batch) and list(batch.stage_names()) == ["al_forward_spectra", "al_emitter_gains", "al_spectral_mac",
-                                                                "al_mac_synthesis", "al_block_synthesis", "al_event_levels"]
-    res = batch.run()
-    res.check_finite()
-    for i, (a, h, sp) in enumerate(zip(clips, irs, specs)):
-        want = orc.render_event(a, h.astype(np.float64), sp.snr, is_moving=sp.is_moving, duration=sp.duration, sr=sr)["spatial"]
-        mr.check_event_rows(res, i, want)
-
-
 @pytest.mark.parametrize("log2_block", [10, 12, 13])
 @pytest.mark.parametrize("p_mult,expect", [(4.3, 612), (11.7, 612), (12.6, 624), (23.9, 624), (24.2, 0)],
                          ids=["P5", "P12", "P13", "P24", "P25_tile_kernel"])
 def test_moving_regimes(gpu, monkeypatch, log2_block, p_mult, expect):
     """The sliding-window accumulate over stored IR spectra (k_spectral_mac_moving): the default at every block size."""
-    set_switch(monkeypatch, "AL_FUSED_MOVING", None)
     mr.run_moving_case(gpu, log2_block, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect)
-
-
-@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(4.3, 10, 14.2, 10604), (11.7, 10, 14.2, 10604), (12.6, 10, 14.2, 10604),
-                                                         (23.9, 10, 14.2, 10604), (2.6, 24, 30.1, 10508), (8.4, 24, 30.1, 10508),
-                                                         (11.72, 24, 30.1, 10508), (17.3, 24, 30.1, 10508), (23.9, 32, 45.4, 10508)],
-                         ids=["nj6_P5", "nj6_P12", "nj6_P13", "nj6_P24", "nj5_P3", "nj5_P9", "nj5_P12", "nj5_P18", "nj5_P24"])
-def test_fused_moving_regimes(gpu, monkeypatch, p_mult, n_irs, k_mult, expect):
-    """k_moving_fused (csrc/al_quad.h; opt-in with AL_FUSED_MOVING=1 at B = 8192): the accumulate transforms the IR partitions
-    itself in the quad layout, no IR spectrum is written (the poisoned workspace stays poisoned).  Both instantiations (streams
-    of at most 5 / 6 blocks), one, two and three passes over the partitions with a ragged last pass, ragged last partition,
-    IRs whose late partitions reach no kept block; every row against the oracle."""
-    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
-    mr.run_moving_case(gpu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=3, E=2)
 
 
 @pytest.mark.parametrize("log2_block,split", [(11, "1"), (12, "1"), (13, "0"), (13, "1"), (14, "1")])
@@ -164,24 +110,10 @@ def test_default_layout_per_block_size(gpu, monkeypatch):
     import numpy as np
 
     set_switch(monkeypatch, "AL_SPLIT", None)
-    set_switch(monkeypatch, "AL_FUSED", None)
     for lb in (10, 12, 13, 14):
         pl = planning.plan_batch([planning.EventSpec(n_samples=3000, n_emitters=1, snr=5.0)], 2, 500, 48000, log2_block=lb)
         batch = gpu.prepare(pl, [np.zeros(3000, np.float32)], np.zeros((2, 1, 500), np.float32))
         assert mr.is_split(batch) == (lb >= 13)
-
-
-def test_quad_layout_alone(gpu, monkeypatch):
-    """The quad slot maps of the split kernels (QuadSlots, csrc/al_fft.h; AL_QUAD=1) WITHOUT the fused kernel: static events through
-    the capsule loop at cfg2's regime and moving events through k_spectral_mac_moving over stored spectra in that layout (the IR,
-    signal and output spectra all permuted the same way; the accumulate must not notice), every row against the oracle."""
-    set_switch(monkeypatch, "AL_QUAD", "1")
-    set_switch(monkeypatch, "AL_FUSED_MOVING", None)
-    res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=3, E=2, expect_fused=False, expect_split=True, expect_quad=True)
-    assert res.plan.n_partitions == 12
-    set_switch(monkeypatch, "AL_TRIM_PARTITIONS", "1")
-    res = mr.run_moving_case(gpu, 13, 11.72, n_irs=24, k_mult=30.1, expect_moving=612, C=3, E=2)
-    assert res.plan.log2_block == 13
 
 
 def test_cfg3_regime_all_rows(gpu):
@@ -191,23 +123,16 @@ def test_cfg3_regime_all_rows(gpu):
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
 
 
-def test_cfg3_regime_all_rows_fused_kernel(gpu, monkeypatch):
-    """The same through k_moving_fused<5,8> (AL_FUSED_MOVING=1: the IR partitions transformed inside the accumulate)."""
-    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
-    res = mr.run_moving_case(gpu, 13, 96000 / 8192, n_irs=32, k_mult=372000 / 8192, expect_moving=10508, C=4, E=2)
-    assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 46
-
-
 def test_cfg4_regime_all_rows(gpu):
     """cfg4's own accumulate at full length: B = 8192, K = 24, P = 6 (4 s clips, 1 s RIRs @ 48 kHz) -> k_spectral_mac_static<12,6,2>;
     3 events x 5 capsules, every row against the oracle."""
-    res = mr.run_static_case(gpu, 13, 3120602, 192000 / 8192, 48000 / 8192, C=5, E=3, expect_fused=False, expect_split=True)
+    res = mr.run_static_case(gpu, 13, 3120602, 192000 / 8192, 48000 / 8192, C=5, E=3, expect_split=True)
     assert res.plan.n_partitions == 6 and int(res.plan.events["n_blocks"].max()) == 24
 
 
 def test_cfg2_regime_all_rows(gpu):
     """cfg2's own regime at full length: B = 8192, K = 24, P = 12 (4 s clips, 2 s RIRs @ 48 kHz), 3 events x 5 capsules."""
-    res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False, expect_split=True)
+    res = mr.run_static_case(gpu, 13, 3121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_split=True)
     assert res.plan.n_partitions == 12 and int(res.plan.events["n_blocks"].max()) == 24
 
 
@@ -215,13 +140,7 @@ def test_cfg2_regime_all_rows_tile_kernels(gpu, monkeypatch):
     """The same through k_spectral_mac<12,12,2,KSPLIT> and the one-transform FFT kernels (round 1's path)."""
     set_switch(monkeypatch, "AL_STATIC_MAC", "0")
     set_switch(monkeypatch, "AL_SPLIT", "0")
-    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=False, expect_split=False)
-
-
-def test_cfg2_regime_all_rows_fused_kernel(gpu, monkeypatch):
-    """The same through the experimental k_mac_synthesis (AL_FUSED=1)."""
-    set_switch(monkeypatch, "AL_FUSED", "1")
-    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_fused=True, expect_split=False)
+    mr.run_static_case(gpu, 13, 1121202, 192000 / 8192, 96000 / 8192, C=5, E=3, expect_split=False)
 
 
 def test_quad16_transforms_all_rows(gpu, monkeypatch):
@@ -260,5 +179,4 @@ def test_random_shapes_over_the_whole_dispatch_space(gpu, monkeypatch, seed):
     beside each other as real scenes mix them, not one regime per batch."""
     set_switch(monkeypatch, "AL_STATIC_MAC", None)
     set_switch(monkeypatch, "AL_EXTRA_FLAGS", None)
-    set_switch(monkeypatch, "AL_FUSED", None)
     mr.run_random_batch(gpu, seed, log2_block=13 if seed % 3 == 2 else 10)

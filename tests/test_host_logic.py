@@ -450,7 +450,7 @@ def test_every_accumulate_instantiation_is_named_by_a_gpu_test():
 
     out = subprocess.check_output(["nm", "-C", _hip.DEFAULT_LIB]).decode()
     syms = {line.split(" ", 2)[2] for line in out.splitlines()
-            if ("k_spectral_mac" in line or "k_moving_fused" in line) and "__device_stub__" not in line}
+            if "k_spectral_mac" in line and "__device_stub__" not in line}
     assert len(syms) >= 40                                  # 12 x {one k-tile, pair, LDS ring} + 2 two-unit + tile + moving kernels
     asserted, unpinned = mr.asserted_codes(), []
     for sym in sorted(syms):
@@ -484,7 +484,7 @@ def _same_optional(a, b):
 def test_c_planner_tables_equal_the_numpy_planner(seed):
     """al_plan_create / al_plan_emitter_parts / al_workspace_bytes (what audiblelight_amd/plan.py calls) against the numpy
     planner of rounds 1-3 (tests/plan_reference.py): every table bit for bit on random batches of static, moving and tiled
-    events, every block size, with and without the fused-moving emitter table."""
+    events, every block size."""
     from tests import plan_reference as ref
 
     rng = np.random.default_rng(900 + seed)
@@ -502,7 +502,6 @@ def test_c_planner_tables_equal_the_numpy_planner(seed):
                (b.audio_floats, b.spatial_floats, b.xspec_blocks, b.yspec_blocks, b.n_partials, b.n_emitters)
         pa, pb = a.emitter_parts(), b.emitter_parts()
         assert _same_optional(pa, pb)
-        assert _same_optional(a.fused_moving_parts(pa), b.fused_moving_parts(pb))
         assert a.workspace_bytes() == b.workspace_bytes() and a.max_nj_sliding() == b.max_nj_sliding()
         assert _hip.get_library().call("al_workspace_bytes", a._c_plan()) == b.workspace_bytes()   # the plan owns its handle
 
@@ -550,7 +549,7 @@ def test_c_planner_edge_cases():
     lib = _hip.get_library()
     empty = planning.plan_batch([], 3, 1000, 8000)
     assert len(empty.events) == 0 and empty.n_emitters == 0 and empty.n_partitions == 0 and empty.workspace_bytes() > 0
-    assert empty.emitter_parts() is None and empty.fused_moving_parts(None) is None and empty.chunks(2)[0]["n_events"] == 0
+    assert empty.emitter_parts() is None and empty.chunks(2)[0]["n_events"] == 0
     pl = planning.plan_batch([planning.EventSpec(3000, 1, 5.0), planning.EventSpec(2000, 0, 5.0, emitter0=1)], 2, 500, 8000, log2_block=10)
     ch = _hip.AlChunk()
     with pytest.raises(_hip.HipError, match="bad chunk range"):

@@ -64,24 +64,6 @@ def test_emu_moving_regimes(emu, p_mult, expect):
     mr.run_moving_case(emu, 10, p_mult, n_irs=10, k_mult=14.2, expect_moving=expect, C=2, E=1)
 
 
-@pytest.mark.parametrize("p_mult,n_irs,k_mult,expect", [(2.6, 5, 6.3, 10508), (9.3, 8, 11.6, 10604), (12.4, 24, 30.1, 10508)],
-                         ids=["nj5_P3", "nj6_P10_three_passes", "nj5_P13_two_passes"])
-def test_emu_fused_moving_kernel(emu, monkeypatch, p_mult, n_irs, k_mult, expect):
-    """k_moving_fused (csrc/al_quad.h, B = 8192) under emulation: the fold of a partition into each quad tile, the four
-    2048-point transforms per round, the real-FFT unpacking of tile 0, the LDS stage, passes over the partitions that add to
-    stored blocks; the IR spectra workspace stays poisoned.  Every row against the oracle."""
-    set_switch(monkeypatch, "AL_FUSED_MOVING", "1")
-    mr.run_moving_case(emu, 13, p_mult, n_irs=n_irs, k_mult=k_mult, expect_moving=expect, C=2, E=1)
-
-
-def test_emu_quad_layout_alone(emu, monkeypatch):
-    """The quad slot maps of the split kernels (QuadSlots, csrc/al_fft.h) without the fused kernel (AL_QUAD=1): static events
-    through the capsule loop, moving ones through k_spectral_mac_moving over stored spectra in that layout."""
-    set_switch(monkeypatch, "AL_FUSED_MOVING", "0")
-    set_switch(monkeypatch, "AL_QUAD", "1")
-    mr.run_static_case(emu, 13, 3120301, 6.5, 2.5, C=2, E=1, expect_split=True, expect_quad=True)
-
-
 def test_emu_quad16_transforms(emu, monkeypatch):
     """csrc/al_quad16.h under emulation (B = 16384 as four 4096-point tiles): a run of three IR partitions with a ragged last one
     (the prefetch hand-over between partitions), interior and edge signal windows, the rolled general signal path with cross-fade
@@ -97,13 +79,6 @@ def test_emu_quad16_transforms(emu, monkeypatch):
     mr.run_separate_forward_launches(emu, 14)
     set_switch(monkeypatch, "AL_QUAD16", "0")
     mr.run_static_case(emu, 14, 3120201, 2.2, 1.5, C=1, E=1, expect_split=False, expect_quad=False)
-
-
-def test_emu_fused_static_kernel(emu, monkeypatch):
-    """k_mac_synthesis (B = 8192) under emulation: three k-tiles with a ragged last one, a partly empty partition tile,
-    the bin-0 fix-up, the LDS hand-over into the transform layout; every row against the oracle."""
-    set_switch(monkeypatch, "AL_FUSED", "1")
-    mr.run_static_case(emu, 13, 1121202, 9.3, 5.002, C=1, E=1, expect_fused=True)
 
 
 def test_emu_split_layout_transforms(emu, monkeypatch):

@@ -176,7 +176,7 @@ class Ambience:
     def __init__(self, channels: int, duration: float, alias: str, filepath: Optional[Union[str, Path]] = None,
                  noise: Optional[Union[str, float]] = None, ref_db: Optional[float] = config.DEFAULT_REF_DB,
                  sample_rate: Optional[int] = config.SAMPLE_RATE, clip: Optional[np.ndarray] = None,
-                 rng: Optional[str] = None, **kwargs):
+                 rng: Optional[str] = None, device_seed: Optional[int] = None, **kwargs):
         for name, val in (("channels", channels), ("sample_rate", sample_rate), ("duration", duration)):
             if not isinstance(val, (int, float, np.integer, np.floating)) or isinstance(val, bool):
                 raise TypeError(f"Expected a numeric input for {name}, but got {type(val)}")
@@ -207,6 +207,12 @@ class Ambience:
         self._device = None
         self._scaled = None
         self.device_shape = None
+        # device-drawn "gaussian" noise without a seed= keyword: the key of this object's realisation is drawn HERE, once, so
+        # that to_dict() is the same before and after the first draw (``device_seed``: a key of its own that __eq__ ignores --
+        # two Ambiences built from the same arguments stay equal, as in the reference, and each still reproduces its own noise)
+        self._entropy = None
+        if self.rng == "device" and self.beta == "gaussian" and self.noise_kwargs.get("seed") is None:
+            self._entropy = _seed64(device_seed)
 
     @property
     def is_audio_loaded(self) -> bool:
@@ -335,8 +341,8 @@ class Ambience:
         # rng="host" made under AL_AMBIENCE_RNG=device
         if self.rng != "host" or default_rng_mode() != "host":
             d["rng"] = self.rng
-        if self.rng == "device" and self.beta == "gaussian" and getattr(self, "_entropy", None) is not None:
-            d["noise_kwargs"] = dict(self.noise_kwargs, seed=self._entropy)   # the realisation this object drew, reproducible from its dictionary
+        if self._entropy is not None:
+            d["device_seed"] = self._entropy     # the realisation this object draws, reproducible from its dictionary
         return d
 
     @classmethod
@@ -346,10 +352,16 @@ class Ambience:
                 raise KeyError(f"Missing key: '{k}'")
         return cls(channels=input_dict["channels"], sample_rate=input_dict["sample_rate"], alias=input_dict["alias"],
                    filepath=input_dict["filepath"], duration=input_dict["duration"], noise=input_dict["beta"],
-                   ref_db=input_dict["ref_db"], rng=input_dict.get("rng"), **input_dict["noise_kwargs"])
+                   ref_db=input_dict["ref_db"], rng=input_dict.get("rng"), device_seed=input_dict.get("device_seed"),
+                   **input_dict["noise_kwargs"])
 
     def __eq__(self, other: Any) -> bool:
-        return isinstance(other, Ambience) and self.to_dict() == other.to_dict()
+        if not isinstance(other, Ambience):
+            return False
+        mine, theirs = self.to_dict(), other.to_dict()
+        mine.pop("device_seed", None)
+        theirs.pop("device_seed", None)
+        return mine == theirs
 
     def __str__(self) -> str:
         return f"'Ambience' with alias '{self.alias}' (currently {'loaded' if self.audio is not None else 'unloaded'})."

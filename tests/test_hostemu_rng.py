@@ -133,7 +133,13 @@ def test_normality_of_the_draws():
 def test_ambience_cls(noise, normalize):   # :107-138
     cls = amb.Ambience(4, 0.25, noise=noise, alias="tester", sample_rate=8000, rng="device")
     assert isinstance(cls.to_dict(), dict) and cls.to_dict().get("rng") == "device"
+    before = cls.to_dict()
+    twin = amb.Ambience(4, 0.25, noise=noise, alias="tester", sample_rate=8000, rng="device")
+    assert cls == twin          # equal at construction (the reference compares dictionaries; device_seed is not part of equality)
     loaded = cls.load_ambience(normalize=normalize)
+    # to_dict is pure: the same before and after audio exists (a "gaussian" object holds its key from construction on) ...
+    assert cls.to_dict() == before and cls.to_dict()["noise_kwargs"] == {} and cls == twin
+    assert ("device_seed" in before) == (noise == "gaussian")
     assert loaded.shape == (4, 2000)
     for channel in loaded:
         if normalize:

@@ -1,59 +1,109 @@
 """Regenerate the two result tables of DESIGN.md (section 5 kernel table, section 7 config table) from the round's profile files:
-profiles/r04_cfgN_kernel_stats.csv, profiles/pmc_traffic.json, profiles/r04_bench_cfgN.json.   python3 profiles/tools/design_tables.py"""
+profiles/<TAG>_cfgN_kernel_stats.csv, profiles/pmc_traffic.json, profiles/<TAG>_bench_cfgN.json.
+    python3 profiles/tools/design_tables.py [TAG]        (default r05)
+The tables sit between the markers <!-- kernel-table --> / <!-- /kernel-table --> and <!-- results-table --> / <!-- /results-table -->
+(a fresh DESIGN.md carries @@KERNEL_TABLE@@ / @@RESULTS_TABLE@@ instead)."""
 import csv
 import json
 import os
 import re
+import sys
 
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 p = os.path.join(R, "DESIGN.md")
 s = open(p).read()
 t = json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))
 CFGS = ("cfg2", "cfg3", "cfg4", "cfg5")
 LB = {"cfg2": 13, "cfg3": 13, "cfg4": 13, "cfg5": 14}
+STAGES = (("forward_spectra", "al_forward_spectra"), ("spectral_mac", "al_spectral_mac"), ("block_synthesis", "al_block_synthesis"),
+          ("k_mixdown", "al_mixdown"), ("emitter_gains", "al_emitter_gains"), ("event_levels", "al_event_levels"))
 
 
 def kms(c):
     out = {}
-    for r in csv.DictReader(open(os.path.join(R, "profiles", f"r04_{c}_kernel_stats.csv"))):
-        for key, stage in (("forward_spectra", "f"), ("spectral_mac", "m"), ("block_synthesis", "s"), ("k_mixdown", "x"), ("emitter_gains", "g"), ("event_levels", "l")):
+    for r in csv.DictReader(open(os.path.join(R, "profiles", f"{TAG}_{c}_kernel_stats.csv"))):
+        for key, stage in STAGES:
             if key in r["Name"]:
                 out[stage] = out.get(stage, 0) + float(r["AverageNs"]) / 1e6
     return out
 
 
-def cell(c, stage, key, bold=False):
-    ms, gb = kms(c)[stage], t[f"{c}/log2_block={LB[c]}"][key] / 1e9
-    txt = f"{ms:.3f}, {gb:.2f}, {gb / ms:.1f}" if ms < 1 else f"{ms:.2f}, {gb:.1f}, {gb / ms:.1f}"
-    return f"**{txt}**" if bold else txt
-
-
-d = {c: json.loads(open(os.path.join(R, "profiles", f"r04_bench_{c}.json")).read().strip().splitlines()[-1]) for c in CFGS}
-d2b = json.loads(open(os.path.join(R, "profiles", "r04_bench_cfg2_steps20.json")).read().strip().splitlines()[-1])
-tot = {c: sum(t[f"{c}/log2_block={LB[c]}"].values()) / 1e9 for c in CFGS}
-small = {c: kms(c)["g"] + kms(c)["l"] for c in CFGS}
+d = {c: json.loads(open(os.path.join(R, "profiles", f"{TAG}_bench_{c}.json")).read().strip().splitlines()[-1]) for c in CFGS}
+d20 = json.loads(open(os.path.join(R, "profiles", f"{TAG}_bench_cfg2_steps20.json")).read().strip().splitlines()[-1])
 k = {c: kms(c) for c in CFGS}
-fmt = lambda v: format(int(round(v)), ",").replace(",", " ")
-fr = lambda c: f"{d[c]['roofline']['frac']:.3f} / {d[c]['roofline']['path_frac']:.3f}"
+traffic = {c: t[f"{c}/log2_block={LB[c]}"] for c in CFGS}
+valu = {c: t.get(f"{c}/log2_block={LB[c]}/valu_insts", {}) for c in CFGS}
+tot = {c: sum(traffic[c].values()) / 1e9 for c in CFGS}
+fmt = lambda v: format(int(round(v)), ",").replace(",", " ")   # noqa: E731
+ISSUE = 256 * 4 * 2.4e9 / 2.0
 
-a = s.index("| forward transforms (IR partitions + signal windows): `k_forward_spectra_split<13>`")
-b = s.index("Every kernel moves the bytes its row says")
-s = s[:a] + f"""| forward transforms (IR partitions + signal windows): `k_forward_spectra_split<13>` (two 4096-point FFTs per window); cfg5 `k_forward_spectra_quad16` (four per window of twice the size) | {cell('cfg2', 'f', 'al_forward_spectra')} | {cell('cfg3', 'f', 'al_forward_spectra')} | {cell('cfg4', 'f', 'al_forward_spectra')} | {cell('cfg5', 'f', 'al_forward_spectra')} |
-| accumulate: `k_spectral_mac_static<12,P,NKTW>` (cfg2 P = 12, two k-tiles; cfg4 P = 6; cfg5 P = 12, one k-tile), `k_spectral_mac_moving<6,12,1>` (cfg3) | {cell('cfg2', 'm', 'al_spectral_mac', True)} | {cell('cfg3', 'm', 'al_spectral_mac')} | {cell('cfg4', 'm', 'al_spectral_mac')} | {cell('cfg5', 'm', 'al_spectral_mac', True)} |
-| inverse transforms + overlap-save: `k_block_synthesis_split<13>`; cfg5 `k_block_synthesis_quad16` | {cell('cfg2', 's', 'al_block_synthesis')} | {cell('cfg3', 's', 'al_block_synthesis')} | {cell('cfg4', 's', 'al_block_synthesis', True)} | {cell('cfg5', 's', 'al_block_synthesis')} |
-| `k_mixdown` | {cell('cfg2', 'x', 'al_mixdown')} | {cell('cfg3', 'x', 'al_mixdown')} | {cell('cfg4', 'x', 'al_mixdown')} | {cell('cfg5', 'x', 'al_mixdown')} |
-| `k_emitter_gains`, `k_event_levels` | {small['cfg2']:.3f} | {small['cfg3']:.3f} | {small['cfg4']:.3f} | {small['cfg5']:.3f} |
-| scene (bench, median of 3 x K steps; box-to-box spread of the pool about 3 %; kernel rows above are from the profiler runs of the same box) | **{d['cfg2']['ms_per_step']:.2f} ms** (2.63-2.74 over the boxes), {tot['cfg2']:.2f} GB | **{d['cfg3']['ms_per_step']:.2f} ms** (6.6-6.9), {tot['cfg3']:.2f} GB | **{d['cfg4']['ms_per_step']:.2f} ms**, {tot['cfg4']:.2f} GB | **{d['cfg5']['ms_per_step']:.2f} ms** (13.7-14.2; round 3 and B = 8192: 14.9-15.1), {tot['cfg5']:.1f} GB |
-| algorithmic bytes (SURVEY 8d), `roofline.frac` / `path_frac` | 1.204 GB: {fr('cfg2')} | 6.68 GB: {fr('cfg3')} | 0.406 GB: {fr('cfg4')} | 7.13 GB: {fr('cfg5')} |
 
-""" + s[b:]
-a = re.search(r"\| cfg2 \(headline\) \| \d", s).start()
-b = s.index("cfg2, cfg3 and cfg4 are unchanged from round 3 within box-to-box spread")
-s = s[:a] + f"""| cfg2 (headline) | {d['cfg2']['ms_per_step']:.2f} ({d2b['ms_per_step']:.2f} with the driver's `--steps 20`; 2.63-2.74 over the boxes of the pool) | **{fmt(round(d['cfg2']['value'], -2))}** (21 900-22 800) | `al_spectral_mac` {k['cfg2']['m']:.3f} ms | {fr('cfg2')} | {tot['cfg2']:.2f} GB vs 1.204 GB = 11.9x | {d['cfg2']['cpu_baseline']['value']:.1f} / **14.3 measured in full** ({d['cfg2']['cpu_baseline_all_cores']['value']:.1f} from the default bounded sample of this run, 12-15 across runs) |
-| cfg3 (16 moving events x 32 IRs) | {d['cfg3']['ms_per_step']:.2f} (6.6-6.9 over the boxes) | {fmt(d['cfg3']['value'])} | `al_forward_spectra` {k['cfg3']['f']:.2f} ms | {fr('cfg3')} | {tot['cfg3']:.2f} GB vs 6.68 GB = 5.4x | 0.64 (1 of 16 events, 8 of 32 IRs, extrapolated) |
-| cfg4 (30 s scene, 32 events, 1 s RIR) | {d['cfg4']['ms_per_step']:.2f} | {fmt(d['cfg4']['value'])} | `al_block_synthesis` {k['cfg4']['s']:.3f} ms | {fr('cfg4')} | {tot['cfg4']:.2f} GB vs 0.406 GB = 15.1x | 5.0 (whole scene) |
-| cfg5 (64 capsules, 128 events, 4 s RIR, ambience, folded FX; B = 16384) | **{d['cfg5']['ms_per_step']:.2f}** (13.7-14.2 over the boxes; round 3: 14.9-15.1) | **{fmt(d['cfg5']['value'])}** | `al_spectral_mac` {d['cfg5']['roofline']['kernel_ms']['al_spectral_mac']:.2f} ms in the bench run ({k['cfg5']['m']:.2f} under the profiler; 26.0 GB, 4.9-5.2 TB/s) | {fr('cfg5')} | {tot['cfg5']:.1f} GB vs 7.13 GB = 10.2x | 0.73 (4 of 128 events, extrapolated) |
+def cell(c, stage):
+    ms, gb = k[c][stage], traffic[c][stage] / 1e9
+    iss = valu[c].get(stage, 0) / ISSUE / (ms * 1e-3) if valu[c].get(stage) else None
+    gf = d[c]["roofline"].get("gflops_by_stage", {}).get(stage)
+    txt = (f"{ms:.3f} ms, {gb:.2f} GB, {gb / ms:.1f} TB/s" if ms < 1 else f"{ms:.2f} ms, {gb:.1f} GB, {gb / ms:.1f} TB/s")
+    if gf:
+        txt += f"; {gf / 1e3:.1f} TFLOP/s"
+    if iss:
+        txt += f", issue {iss:.2f}"
+    dom = max((st for _, st in STAGES[:4]), key=lambda st: k[c][st])
+    return f"**{txt}**" if stage == dom else txt
 
-""" + s[b:]
+
+names = {"al_forward_spectra": "forward transforms (IR partitions + signal windows): `k_forward_spectra_split<13>`; cfg5 `k_forward_spectra_quad16`",
+         "al_spectral_mac": "accumulate: `k_spectral_mac_static<12,P,NKTW>` (cfg2 P = 12, two k-tiles; cfg4 P = 6; cfg5 P = 12 at B = 16384), `k_spectral_mac_moving<6,12,1>` (cfg3)",
+         "al_block_synthesis": "inverse transforms + overlap-save + level partials: `k_block_synthesis_split<13>`; cfg5 `k_block_synthesis_quad16`",
+         "al_mixdown": "`k_mixdown`"}
+rows = ["| Kernel (default dispatch): ms, PMC bytes, rate on them; plan-counted TFLOP/s, VALU issue fraction | cfg2 | cfg3 | cfg4 | cfg5 (B = 16384) |",
+        "|---|---|---|---|---|"]
+for stage, label in names.items():
+    rows.append(f"| {label} | " + " | ".join(cell(c, stage) for c in CFGS) + " |")
+rows.append("| `k_emitter_gains` + `k_event_levels` | " + " | ".join(f"{k[c]['al_emitter_gains'] + k[c]['al_event_levels']:.3f} ms" for c in CFGS) + " |")
+rows.append("| scene: bench `ms_per_step` (median of 3 × K steps; the pool's boxes differ by about 3 %), PMC bytes | "
+            + " | ".join(f"**{d[c]['ms_per_step']:.2f} ms**, {tot[c]:.1f} GB" for c in CFGS) + " |")
+alg = {c: d[c]["roofline"]["algorithmic_bytes_per_launch"] / 1e9 for c in CFGS}
+rows.append("| algorithmic bytes (SURVEY 8d); `roofline.frac` / `path_frac`; `traffic_ratio` | "
+            + " | ".join(f"{alg[c]:.3f} GB; {d[c]['roofline']['frac']:.3f} / {d[c]['roofline']['path_frac']:.3f}; {tot[c] / alg[c]:.1f}×" for c in CFGS) + " |")
+kernel_table = "<!-- kernel-table -->\n" + "\n".join(rows) + "\n<!-- /kernel-table -->"
+
+
+def parity_of(c):
+    par = d[c].get("parity")
+    return f"{par['rel_rms']:.1e} / {par['max_abs_over_peak']:.1e} ({par['events']} events, {par['rows']} × {fmt(par['samples'])})" if par else "—"
+
+
+def cpu_of(c):
+    one = d[c].get("cpu_baseline", {})
+    allc = d[c].get("cpu_baseline_all_cores")
+    txt = f"{one.get('value', float('nan')):.2f}" + (" (extrapolated)" if one.get("extrapolated") else "")
+    if allc and "value" in allc:
+        txt += f" / {allc['value']:.1f} on {allc['cores']} cores"
+    return txt
+
+
+res = ["| Config | ms per scene | scene-s/s | dominant kernel | `frac` / `path_frac` | GFLOP/s (dominant), fraction of 157.3 TF | parity vs oracle: rel. RMS / max-abs | oracle: 1 core / all allowed cores |",
+       "|---|---|---|---|---|---|---|---|"]
+label = {"cfg2": "cfg2 (headline)", "cfg3": "cfg3 (16 moving events × 32 IRs)", "cfg4": "cfg4 (30 s scene, 32 events, 1 s RIR)",
+         "cfg5": "cfg5 (64 capsules, 128 events, 4 s RIR, ambience, folded FX)"}
+for c in CFGS:
+    r = d[c]["roofline"]
+    ms = f"{d[c]['ms_per_step']:.2f}" + (f" ({d20['ms_per_step']:.2f} with the driver's `--steps 20`)" if c == "cfg2" else "")
+    res.append(f"| {label[c]} | {ms} | **{fmt(d[c]['value'])}** | `{r['kernel']}` {r['kernel_ms'][r['kernel']]:.3f} ms | {r['frac']:.3f} / {r['path_frac']:.3f} | "
+               f"{fmt(r['gflops'])}, {r['valu_frac_of_peak']:.2f} | {parity_of(c)} | {cpu_of(c)} |")
+e2e, drop = d["cfg2"].get("end_to_end"), d["cfg2"].get("end_to_end_dropin")
+tail = ""
+if e2e and drop:
+    tail = (f"\n\nPCIe-inclusive on the same run (never the headline): pipelined batch driver **{fmt(e2e['value'])} scene-s/s** "
+            f"({e2e['ms_per_scene']:.1f} ms per cfg2 scene), synchronous drop-in `Scene.generate()` **{fmt(drop['value'])}** ({drop['ms_per_scene']:.1f} ms).")
+results_table = (f"<!-- results-table -->\nRound-5 results (`profiles/{TAG}_bench_*.json`: one MI355X, host {d['cfg2']['cpu_baseline']['cpu_model']}, final sources "
+                 f"`{d['cfg2']['config']['source_hash']}`; kernel rows in section 5):\n\n" + "\n".join(res) + tail + "\n<!-- /results-table -->")
+
+for marker, block, tag in (("@@KERNEL_TABLE@@", kernel_table, "kernel-table"), ("@@RESULTS_TABLE@@", results_table, "results-table")):
+    if marker in s:
+        s = s.replace(marker, block)
+    else:
+        s = re.sub(rf"<!-- {tag} -->.*?<!-- /{tag} -->", lambda m, b=block: b, s, flags=re.S)
 open(p, "w").write(s)
-print("DESIGN.md tables regenerated")
+print("DESIGN.md tables regenerated from", TAG)

@@ -1752,8 +1752,8 @@ int64_t al_stft_workspace_floats(int64_t series, int32_t fft_size) {
 
 int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t win_size, int32_t hop_size, float *spec,
             float *workspace, al_stream_t stream) {
-  if (!y || !spec || !workspace || rows <= 0 || n <= 0 || win_size <= 0 || hop_size <= 0 || win_size < hop_size ||
-      fft_size < win_size)
+  // fft_size < win_size is legal in the reference: rfft(frames, n=fft_size) crops every windowed frame to its first fft_size samples
+  if (!y || !spec || !workspace || rows <= 0 || n <= 0 || win_size <= 0 || hop_size <= 0 || win_size < hop_size || fft_size <= 0)
     return fail(AL_E_BADARG, "bad stft arguments");
   if (!smooth_length(fft_size)) return fail(AL_E_UNSUPPORTED, "stft: fft_size must factor into 2, 3, 5, 7");
   hipStream_t st = (hipStream_t)stream;

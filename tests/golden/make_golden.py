@@ -249,7 +249,8 @@ def stft_vectors(syn):
 def geometry_vectors(syn):
     """G14: moving events rendered with OTHER STFT geometries than the defaults (synthesize.py:507-516 exposes fft_size /
     win_size / hop_size and :277-310 honours any values the framing accepts): win != 2*hop, fft < 2*win - 1 (time-aliased
-    frames), 75 % overlap, and a scaled copy of the default geometry; plus the geometries the reference itself REFUSES
+    frames), 75 % overlap, a scaled copy of the default geometry, non-power-of-two sizes, fft < win (frames cropped by
+    rfft(n=fft_size)); plus the geometries the reference itself REFUSES
     (istft_overlap_synthesis needs fft <= 2*hop + win: numpy raises a broadcast ValueError otherwise; stft needs win >= hop:
     np.pad raises).  A file of its own with its own seed: the other golden files are untouched."""
     rng = np.random.default_rng(20261004)
@@ -257,7 +258,7 @@ def geometry_vectors(syn):
     a = make_clip(rng, 6000)
     h = make_irs(rng, n_caps, n_ir, 1500)
     out = dict(g14_audio=a, g14_irs=h.astype(np.float32))
-    geoms = [(512, 256, 192), (256, 256, 128), (384, 256, 64), (1024, 512, 256), (512, 384, 128), (300, 200, 100)]
+    geoms = [(512, 256, 192), (256, 256, 128), (384, 256, 64), (1024, 512, 256), (512, 384, 128), (300, 200, 100), (192, 256, 128)]
     out["g14_geometries"] = np.array(geoms)
     for fft_size, win, hop in geoms:
         ev = FakeEvent("g14", a, n_ir, snr=11.0, sr=sr, is_moving=True)

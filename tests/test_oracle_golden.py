@@ -223,14 +223,14 @@ GEOMETRY = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "r
 
 
 def test_g14_other_stft_geometries():
-    """G14 (tests/golden/make_golden.py::geometry_vectors): the reference's render of one moving event under six STFT
+    """G14 (tests/golden/make_golden.py::geometry_vectors): the reference's render of one moving event under seven STFT
     geometries -- win != 2*hop, fft < 2*win - 1, 75 % overlap, a scaled default, win > fft/2 with hop = win/3, non-power-of-two
-    sizes -- reproduced by the oracle's literal STFT-domain restatement to 1e-10; where the envelope identity holds
+    sizes, fft < win -- reproduced by the oracle's literal STFT-domain restatement to 1e-10; where the envelope identity holds
     (win == 2*hop, fft >= 2*win - 1: the scaled default) the envelope form agrees as well."""
     with np.load(GEOMETRY) as z:
         z = {k: z[k] for k in z.files}
     a, h = z["g14_audio"], z["g14_irs"].astype(np.float64)
-    assert len(z["g14_geometries"]) == 6 and len(z["g14_refused"]) == 3
+    assert len(z["g14_geometries"]) == 7 and len(z["g14_refused"]) == 3
     for fft_size, win, hop in z["g14_geometries"].tolist():
         tag = f"g14_{fft_size}_{win}_{hop}"
         got = orc.render_event(a, h, 11.0, ref_db=-65, is_moving=True, duration=len(a) / 8000, sr=8000, nfft=fft_size, win=win,

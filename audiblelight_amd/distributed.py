@@ -59,7 +59,8 @@ def host_share(local_rank: int, local_world: int, device_index: Optional[int] = 
         except Exception:  # noqa: BLE001 -- no sysfs entry, no such attribute: fall through to the equal slice
             mine = []
     if mine:
-        # several GPUs usually share one NUMA node: the ranks of that node split its CPUs between them
+        # several GPUs usually share one NUMA node: their ranks share that node's CPUs (the scheduler balances them inside the
+        # set), each with its pools capped at the per-rank share
         out["threads"] = max(1, min(out["threads"], len(mine)))
     else:
         per = max(1, len(usable) // local_world)

@@ -102,15 +102,26 @@ def _permuted(buf, shape, axes):
     return np.ascontiguousarray(buf[:n].reshape(shape).transpose(axes)).reshape(-1)
 
 
-def _tv_chain_on_device(r, ir_dev, n_ch: int, n_irs: int, ir_pitch: int, audio_dev, n_audio: int, duration: float, sr: float,
-                        fft_size: int, win_size: int, hop_size: int):
+def _compact_rows(buf, rows: int, pitch: int, length: int):
+    """rows x pitch -> contiguous rows x length (the first ``length`` elements of every row); a copy, no arithmetic."""
+    if hasattr(buf, "permute"):
+        return buf[: rows * pitch].view(rows, pitch)[:, :length].contiguous().view(-1)
+    return np.ascontiguousarray(buf[: rows * pitch].reshape(rows, pitch)[:, :length]).reshape(-1)
+
+
+def _tv_chain_on_device(r, ir_dev, n_ch: int, n_irs: int, ir_len: int, audio_dev, n_audio: int, duration: float, sr: float,
+                        fft_size: int, win_size: int, hop_size: int, ir_pitch: Optional[int] = None):
     """The reference's literal STFT-domain chain (synthesize.py:298-310) on device buffers, for STFT geometries outside the
     envelope form: stft of the IRs and of the clip (al_stft), the frame-domain convolution with the cross-fade weights
-    (al_tv_stft_mac), inverse transforms + overlap-add (al_istft_ola).  ``ir_dev``: (C, N, ir_pitch) float32 rows (zero-padded
-    rows only add all-zero IR frames).  Returns (device (n_out, C) float32, n_out); nothing is synchronised or downloaded."""
+    (al_tv_stft_mac), inverse transforms + overlap-add (al_istft_ola).  ``ir_dev``: (C, N, ir_pitch) float32 rows of which the
+    first ``ir_len`` samples are the IR.  The frame count of the IR spectrogram comes from ``ir_len`` exactly as in the reference
+    (2 * ceil(L / (2 hop)) + 1): frames past it would not be all-zero -- they would window the IR's tail once more -- so rows
+    with a pitch are compacted first (a copy).  Returns (device (n_out, C) float32, n_out); nothing is synchronised or downloaded."""
     mem, lib, st = r.mem, r.lib, r.mem.stream()
     n_freq = fft_size // 2 + 1
-    f_ir = planning.stft_frame_count(ir_pitch, hop_size, lib=lib)
+    if ir_pitch is not None and ir_pitch != ir_len:
+        ir_dev = _compact_rows(ir_dev, n_ch * n_irs, ir_pitch, ir_len)
+    f_ir = planning.stft_frame_count(ir_len, hop_size, lib=lib)
     f_a = planning.stft_frame_count(n_audio, hop_size, lib=lib)
     w = generate_interpolation_matrix(np.linspace(0, duration, n_irs), sr, hop_size, lib=lib)
     n_frames = min(f_a, w.shape[0])
@@ -120,7 +131,7 @@ def _tv_chain_on_device(r, ir_dev, n_ch: int, n_irs: int, ir_pitch: int, audio_d
     rows = n_ch * n_irs
     h_spec = mem.empty(2 * rows * f_ir * n_freq)
     work = mem.empty(lib.call("al_stft_workspace_floats", rows * f_ir, fft_size))
-    lib.call("al_stft", mem.ptr(ir_dev), rows, ir_pitch, fft_size, win_size, hop_size, mem.ptr(h_spec), mem.ptr(work), st)
+    lib.call("al_stft", mem.ptr(ir_dev), rows, ir_len, fft_size, win_size, hop_size, mem.ptr(h_spec), mem.ptr(work), st)
     s_ir = _permuted(h_spec, (n_ch, n_irs, f_ir, n_freq, 2), (2, 3, 0, 1, 4))      # (F_ir, freq, C, N): the reference's layout
     del h_spec
     a_spec = mem.empty(2 * f_a * n_freq)
@@ -417,8 +428,8 @@ def _render_moving_general(r: engine.Renderer, spec, clip, irs: np.ndarray, fft_
     if bufs.get("clip_scale") is not None:   # folded scalar FX / device-side peak normalisation: applied to a copy of the clip
         audio_dev = audio_dev[:n_audio].clone() if hasattr(audio_dev, "clone") else np.array(audio_dev[:n_audio])
         lib.call("al_scale_rows", mem.ptr(audio_dev), n_audio, mem.ptr(bufs["clip_scale"]), st)
-    out, n_out = _tv_chain_on_device(r, bufs["ir"], n_ch, n_irs, pitch, audio_dev, n_audio, float(spec.duration), sample_rate,
-                                     fft_size, win_size, hop_size)
+    out, n_out = _tv_chain_on_device(r, bufs["ir"], n_ch, n_irs, n_ir, audio_dev, n_audio, float(spec.duration), sample_rate,
+                                     fft_size, win_size, hop_size, ir_pitch=pitch)
     # (n_out, C) -> the event's (C, La) block of `spatial`, cut or zero-padded to the clip length (synthesize.py:590)
     lo, keep = int(pl.events["out_off"][0]), min(n_out, n_audio)
     block = bufs["spatial"][lo: lo + n_ch * n_audio]

@@ -83,6 +83,7 @@ print("asan run ok: round-3 kernels")
 
 # round 4: the planner behind the C ABI ran for every batch above (al_plan_create / al_plan_chunk / al_plan_emitter_parts /
 # al_plan_mixdown / al_plan_batch_flags from the sanitized library)
+setenv("AL_SPLIT", None)     # back to the library's own layout policy
 # the quad-tile transforms at B = 16384 (csrc/al_quad16.h): a run of five IR partitions with a ragged last one (the prefetch
 # hand-over), interior and edge signal windows, the rolled general signal path (moving event), the four-tile inverse
 B = 16384

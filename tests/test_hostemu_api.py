@@ -394,6 +394,17 @@ def test_moving_events_under_other_stft_geometries():
         raw = syn.time_variant_convolution(hn, ev, fft_size, win, hop)
         assert raw.shape == z[tag + "_raw"].shape
         assert_parity(raw, z[tag + "_raw"], TOL, what=tag)
+    # an IR whose 4-float padded row (773 -> 776 samples) would cross a 2*hop boundary: the IR spectrogram's frame count must come
+    # from the TRUE length (found by profiles/tools/fuzz_geometry.py, seed 335); against the oracle's literal restatement
+    rng = np.random.default_rng(335)
+    a2 = rng.standard_normal(7535).astype(np.float32)
+    a2 /= np.abs(a2).max()
+    h2 = (rng.standard_normal((2, 3, 773)) * np.exp(-np.arange(773) / 150.0)).astype(np.float32)
+    ev = core.Event("odd", a2, 16000, snr=9.0, n_emitters=3, is_moving=True)
+    syn.render_event_audio(ev, h2, "mic000", ref_db=-60, fft_size=512, win_size=477, hop_size=129)
+    want = orc.render_event(a2, h2.astype(np.float64), 9.0, ref_db=-60, is_moving=True, duration=7535 / 16000, sr=16000, nfft=512, win=477,
+                            hop=129)["spatial"]
+    assert_parity(ev.spatial_audio["mic000"], want, TOL, what="odd IR length")
     # the mixdown takes such an event like any other (same RenderResult): scaled render summed into a scene
     ev = core.Event("g14", a, 8000, snr=11.0, n_emitters=4, is_moving=True, scene_start=0.1)
     syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=512, win_size=256, hop_size=192)

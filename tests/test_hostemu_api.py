@@ -405,6 +405,16 @@ def test_moving_events_under_other_stft_geometries():
     want = orc.render_event(a2, h2.astype(np.float64), 9.0, ref_db=-60, is_moving=True, duration=7535 / 16000, sr=16000, nfft=512, win=477,
                             hop=129)["spatial"]
     assert_parity(ev.spatial_audio["mic000"], want, TOL, what="odd IR length")
+    # clips that reach the renderer with work still to do ON THE DEVICE -- folded scalar FX + peak normalisation (al_clip_scales)
+    # and a device-resident FX chain -- go through the general chain too: the clip the STFT frames is the finished one
+    raw = rng.standard_normal(5000).astype(np.float32) * 0.4
+    for chain, finished in (([aug.Gain(16000, gain_db=-3.0), aug.Invert(16000)], orc.peak_normalise_clip(orc.fx_invert(orc.fx_gain(raw, -3.0)))),
+                            ([aug.Reverse(16000), aug.Gain(16000, gain_db=2.0)], orc.peak_normalise_clip(orc.fx_gain(orc.fx_reverse(raw), 2.0)))):
+        ev = core.Event("fx", raw, 16000, snr=12.0, n_emitters=3, is_moving=True, augmentations=chain)
+        syn.render_event_audio(ev, h2, "mic000", ref_db=-60, fft_size=384, win_size=256, hop_size=64)
+        want = orc.render_event(finished, h2.astype(np.float64), 12.0, ref_db=-60, is_moving=True, duration=5000 / 16000, sr=16000,
+                                nfft=384, win=256, hop=64)["spatial"]
+        assert_parity(ev.spatial_audio["mic000"], want, TOL, what="fx chain + general geometry")
     # the mixdown takes such an event like any other (same RenderResult): scaled render summed into a scene
     ev = core.Event("g14", a, 8000, snr=11.0, n_emitters=4, is_moving=True, scene_start=0.1)
     syn.render_event_audio(ev, h, "mic000", ref_db=-65, fft_size=512, win_size=256, hop_size=192)

@@ -75,6 +75,16 @@ def current() -> Switches:
     return _current
 
 
+def set_env(name: str, value) -> Switches:
+    """Set (value None: remove) one AL_* variable in this process and parse the switches again: for measurement drivers and tests
+    that flip a switch between two renders (profiles/tools/*.py, tests/conftest.py::set_switch)."""
+    if value is None:
+        os.environ.pop(name, None)
+    else:
+        os.environ[name] = str(value)
+    return reload()
+
+
 def reload() -> Switches:
     """Parse the environment again (tests that flip a switch between two renders)."""
     global _current

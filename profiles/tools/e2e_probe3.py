@@ -1,6 +1,7 @@
 """Pipelined batch driver, cfg2: DMA download stream vs kernels writing into page-locked host memory; scene / frames output."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import batch as B, engine, synthetic
 sc = synthetic.make_scene("cfg2")
@@ -8,7 +9,7 @@ r = engine.Renderer()
 jobs = [B.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs.copy() if i else sc.irs, starts=sc.starts, ends=sc.ends, duration=sc.duration, sample_rate=sc.sr, name=f"s{i}") for i in range(4)]
 os.makedirs("/tmp/e2e_out", exist_ok=True)
 for mode in ("dma", "kernel", "dma", "kernel"):
-    os.environ["AL_D2H"] = mode
+    _sw.set_env("AL_D2H", mode)
     for what, kw in (("scene f32 to callback", dict(on_scene=lambda n, a: None, copy_for_callback=False)),
                      ("PCM_16 wav files", dict(output_dir="/tmp/e2e_out")), ("FLOAT wav files", dict(output_dir="/tmp/e2e_out", subtype="FLOAT"))):
       for writers in ((4, 8) if "output_dir" in kw else (1,)):

@@ -2,12 +2,13 @@
 the render switched off."""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import batch as B, engine, synthetic
 sc = synthetic.make_scene("cfg2")
 r = engine.Renderer()
 jobs = [B.SceneJob(specs=sc.specs, clips=sc.clips, irs=sc.irs.copy() if i else sc.irs, starts=sc.starts, ends=sc.ends, duration=sc.duration, sample_rate=sc.sr, name=f"s{i}") for i in range(4)]
-os.environ["AL_H2D"] = "blocking"
+_sw.set_env("AL_H2D", "blocking")
 class NoDown(B.BatchDriver):
     def _download(self, st, want_frames, want_scene, subtype):
         ev = self.torch.cuda.Event(); ev.record(); st.update(landed=ev, host=self._pinned_buffer("scene", self.torch.float32, 32 * 2880000, 0)); return st

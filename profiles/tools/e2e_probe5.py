@@ -2,6 +2,7 @@
 thread), instead of being enqueued early behind an event?"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import batch as B, engine, synthetic
 sc = synthetic.make_scene("cfg2")
@@ -23,7 +24,7 @@ class LateDown(B.BatchDriver):
         st.update(landed=Landed(), host=host)
         return st
 for mode in ("blocking", "async"):
-    os.environ["AL_H2D"] = mode
+    _sw.set_env("AL_H2D", mode)
     for cls in (B.BatchDriver, LateDown):
         dd = cls(r)
         kw = dict(on_scene=lambda n, a: None, copy_for_callback=False, check_finite=False)

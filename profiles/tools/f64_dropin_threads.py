@@ -1,5 +1,6 @@
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np
 from audiblelight_amd import core, engine, synthetic, synthesize as syn
 scene = synthetic.make_scene("cfg2")
@@ -11,7 +12,7 @@ def one(irs):
         sc.add_event(core.Event(f"e{i}", clip, scene.sr, snr=sp.snr, scene_start=scene.starts[i]))
     return sc.generate()["mic000"]
 for threads in (8, 16, 4, 12, 8, 16, 24):
-    os.environ["AL_CONVERT_THREADS"] = str(threads)
+    _sw.set_env("AL_CONVERT_THREADS", str(threads))
     for _ in range(3): one(irs64)
     ts = []
     for _ in range(10):

@@ -2,6 +2,7 @@
 Also float32 IRs for the PCIe-bound reference point."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import engine, synthetic, batch as B
 sc = synthetic.make_scene("cfg2")
@@ -18,5 +19,5 @@ def run(irs, label):
     print(f"{label}: {best / 16 * 1e3:.1f} ms/scene", {k: round(v / 16 * 1e3, 1) for k, v in rep.host_s.items()}, flush=True)
 run(sc.irs, "float32 IRs")
 for threads in [int(x) for x in os.environ.get("CAST_THREADS", "4,8,12,16,24,32,8").split(",")]:
-    os.environ["AL_CONVERT_THREADS"] = str(threads)
+    _sw.set_env("AL_CONVERT_THREADS", str(threads))
     run(irs64, f"float64 IRs, {threads:2d} cast threads")

@@ -1,5 +1,6 @@
 import os, sys, numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 from audiblelight_amd import engine, plan as planning
 from oracle import synth_oracle as orc
 r = engine.Renderer()
@@ -10,14 +11,12 @@ for seed in range(int(os.environ.get("FUZZ_FROM", 0)), int(os.environ.get("FUZZ_
     rng = np.random.default_rng(5000 + seed)
     log2_block = int(rng.integers(10, 15))
     m = seed % 3
-    os.environ["AL_EXTRA_FLAGS"] = str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)) if m == 1 else ("4" if m == 2 else "0")
-    os.environ["AL_FUSED"] = "1" if seed % 2 else "0"     # the experimental fused kernel takes the static events at B = 8192
+    _sw.set_env("AL_EXTRA_FLAGS", str((int(rng.integers(2, 5)) << 16) | (int(rng.integers(2, 5)) << 24)) if m == 1 else ("4" if m == 2 else "0"))
     sr, C = 16000, int(rng.integers(1, 8))
     if seed >= 400:   # long IRs (up to 14 partitions: both accumulate families) at small blocks, transform layout and accumulate kernel at random
         log2_block = int(rng.integers(10, 13))
-        os.environ["AL_FUSED"] = "0"
-        os.environ["AL_SPLIT"] = str(int(rng.integers(0, 2)))
-        os.environ["AL_STATIC_MAC"] = str(int(rng.integers(0, 2)))
+        _sw.set_env("AL_SPLIT", str(int(rng.integers(0, 2))))
+        _sw.set_env("AL_STATIC_MAC", str(int(rng.integers(0, 2))))
     L = int(rng.integers(1, (14 if seed >= 400 else 3) << log2_block))
     specs, clips, irs, col = [], [], [], 0
     for _ in range(int(rng.integers(1, 5))):

@@ -1,6 +1,7 @@
 """cfg2 with the IR cut to fewer taps (P = 12 ... 2 partitions): per-stage ms, capsule-loop accumulate (static_mac=1) vs tile kernels."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import engine, synthetic, plan as planning
 sc = synthetic.make_scene("cfg2")
@@ -9,7 +10,7 @@ for taps in [int(t) for t in os.environ.get('TAPS', '96000,88000,80000,64000,560
     irs = np.ascontiguousarray(np.concatenate([sc.irs, 0.05 * sc.irs, 0.01 * sc.irs], axis=2)[:, :, :taps])
     c, n, l = irs.shape
     for static in ("1", "0"):
-        os.environ["AL_STATIC_MAC"] = static
+        _sw.set_env("AL_STATIC_MAC", static)
         pl = planning.plan_batch(sc.specs, c, l, sc.sr)
         batch = r.prepare(pl, sc.clips, irs)
         for _ in range(3): batch.run()

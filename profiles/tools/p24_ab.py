@@ -2,6 +2,7 @@
 against the tile kernels (AL_STATIC_MAC_MAX_P=16 keeps the old dispatch).  Static events, C=32, E=64, La=192000."""
 import ctypes, os, sys
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np, torch
 from audiblelight_amd import engine, plan as planning
 r = engine.Renderer()
@@ -10,7 +11,7 @@ for Lir in (100000, 125000, 135000, 150000, 170000, 192000):
     for max_p, flags in (("12", "0"), ("18", "0"), ("24", "16384")):    # tile kernels | register / LDS-staged capsule loop | LDS-DMA capsule loop
         if max_p == "18" and Lir > 147456:
             continue
-        os.environ["AL_STATIC_MAC_MAX_P"], os.environ["AL_EXTRA_FLAGS"] = max_p, flags
+        _sw.set_env("AL_STATIC_MAC_MAX_P", max_p); _sw.set_env("AL_EXTRA_FLAGS", flags)
         C, E, La = 32, 64, 192000
         clips = [rng.standard_normal(La).astype(np.float32) for _ in range(E)]
         irs = (rng.standard_normal((C, E, Lir), dtype=np.float32) * np.exp(-np.arange(Lir) / (Lir / 6.9)).astype(np.float32))

@@ -5,6 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
 import numpy as np
 import torch
 from audiblelight_amd import engine, plan as planning
@@ -20,7 +21,7 @@ specs += [planning.EventSpec(n_samples=len(clips[E_static + m]), n_emitters=n_ir
                              duration=len(clips[E_static + m]) / sr) for m in range(2)]
 pl = planning.plan_batch(specs, C, Lir, sr, log2_block=14)
 for run_len in (0, 2, 3, 7):
-    os.environ["AL_EXTRA_FLAGS"] = str(run_len << 24)
+    _sw.set_env("AL_EXTRA_FLAGS", str(run_len << 24))
     r = engine.Renderer()
     batch = r.prepare(pl, clips, irs)
     seen = {}

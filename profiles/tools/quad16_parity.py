@@ -4,7 +4,8 @@ import os
 import sys
 
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
-os.environ["AL_QUAD16"] = "1"
+from audiblelight_amd import switches as _sw   # AL_* switches are parsed once per process: set them through set_env
+_sw.set_env("AL_QUAD16", "1")
 from audiblelight_amd import engine  # noqa: E402
 from tests import mac_regimes as mr  # noqa: E402
 

@@ -443,12 +443,14 @@ class Renderer:
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                 chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
-                audio_dev=None) -> "PreparedBatch":
+                audio_dev=None, emitter_parts: Optional[np.ndarray] = None) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
         ``lanes``: number of workspaces / HIP streams the chunks alternate over (chunk i runs on lane i % lanes),
-        so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another."""
+        so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another.
+        ``emitter_parts``: the caller's own al_batch.emitter_parts (int32 per IR column; 0 = "energies only": the forward transform
+        reads that IR for normalize_irs and neither transforms nor stores it) instead of the planner's."""
         mem = self.mem
         on_its_way = irs if hasattr(irs, "result") else None      # from upload_irs_beside: waited for below, after the staging
         if ir_strides is None and on_its_way is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
@@ -478,6 +480,8 @@ class Renderer:
                        np.array([1 if src.normalize else 0 for src in sources], dtype=np.int32)]
         sw = switches.current()      # parsed once per process (switches.py): nothing on this path reads the environment
         parts = plan.emitter_parts() if sw.trim_partitions else None
+        if emitter_parts is not None:
+            parts = np.ascontiguousarray(emitter_parts, dtype=np.int32)
         if parts is not None:        # al_batch.emitter_parts: IR partitions that cannot reach a kept block are not transformed
             tables.append(parts)
         tabs = mem.upload_tables(tables) if hasattr(mem, "upload_tables") else [mem.upload(t) for t in tables]

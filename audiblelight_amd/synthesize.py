@@ -414,7 +414,8 @@ def _render_moving_general(r: engine.Renderer, spec, clip, irs: np.ndarray, fft_
     n_ch, n_irs, n_ir = irs.shape
     host_clip = engine.as_clip_source(clip)
     pl = planning.plan_batch([spec], n_ch, n_ir, sample_rate, lib=lib)          # layout + tables only (default geometry)
-    batch = r.prepare(pl, [clip], irs)
+    # emitter_parts = 0 everywhere: the forward pass only takes the IR energies (normalize_irs), no partition spectrum is made
+    batch = r.prepare(pl, [clip], irs, emitter_parts=np.zeros(n_irs, dtype=np.int32))
     desc = batch.descs[0]
     for name in ("al_forward_spectra", "al_emitter_gains"):
         lib.call(name, ct.byref(desc), st)

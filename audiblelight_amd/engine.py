@@ -520,7 +520,7 @@ class Renderer:
         # decision (al_plan_batch_flags, csrc/al_plan.cpp): a C host gets the same dispatch from the same plan
         # (tests/c_caller/render_planned.c).  The A/B switches of switches.py can force other paths.
         for desc, chunk in zip(descs, chunks):
-            desc.flags |= plan.batch_flags(chunk, lib=self.lib)
+            desc.flags |= plan.batch_flags(chunk)
             if sw.forces_dispatch:
                 desc.flags = self._forced_dispatch(desc, plan, sw)
         if fold:   # A13 on the device: peak normalisation + folded scalar FX, no clip statistics cross PCIe

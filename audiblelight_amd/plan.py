@@ -178,9 +178,10 @@ class BatchPlan:
             out.append({name: int(getattr(ch, name)) for name, _ in _hip.AlChunk._fields_})
         return out
 
-    def batch_flags(self, chunk: Optional[dict] = None, lib=None) -> int:
+    def batch_flags(self, chunk: Optional[dict] = None) -> int:
         """al_batch.flags of a chunk (one of ``chunks()``; None = the whole plan): the library's dispatch policy --
-        layout flags for the block size, accumulate flags for the chunk's event mix (al_plan_batch_flags)."""
+        layout flags for the block size, accumulate flags for the chunk's event mix (al_plan_batch_flags; asked of the library
+        that made this plan's handle)."""
         if not len(self.events):
             return 0
         flags = ct.c_int32(0)

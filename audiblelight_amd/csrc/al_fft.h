@@ -408,7 +408,7 @@ __device__ __forceinline__ void fft_regs_to_regs(float2 (&v)[G::E], float2 *s, c
 }
 
 // ---- where slot q of a spectrum half lives
-// PlainSlots: at q (the layouts of DESIGN.md sections 2 and 5.2).
+// PlainSlots: at q (the layouts of DESIGN.md sections 2 and 5).  The slot map is a template parameter of the packing steps.
 struct PlainSlots {
   static __device__ __forceinline__ void store_even(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }
   static __device__ __forceinline__ void store_odd(float2 *half, int q, float2 v) { stream_store<4>(half + q, v); }

@@ -6,7 +6,7 @@
 // 16384-point transform per window needs 139 KB of LDS (one workgroup per CU), two 8192-point ones (split layout) 68 KB each
 // (two); cfg5 at B = 16384 through them: 17.0 ms per scene against 15.0 at B = 8192.  The 4096-point transform (35 KB of LDS,
 // three passes of radix 16) is the one this chip runs well.  So a window's spectrum at B = 16384 is made of FOUR independent
-// 4096-point transforms: the quad tiles of csrc/al_quad.h, here as the NATIVE layout of the block (no slot map):
+// 4096-point transforms ("quad tiles"), the NATIVE layout of a block at this size (no slot map):
 //   slots [0, Q)   T0 = W[4i]   = rFFT_{2Q}(a)[i],  a[t] = s[t] + s[t + 2Q]          (slot 0 packs W[0] and W[B])
 //   slots [Q, 2Q)  T1 = W[8i+2] = FFT_Q( ((s0 - s2) - i (s1 - s3)) w^2 )
 //   slots [2Q,3Q)  T2 = W[8i+1] = FFT_Q( ((d0 - i d2) + c8 (d1 - i d3)) w   )
@@ -17,13 +17,13 @@
 // w2 = (s - d) / 2.  (Checked in numpy before it was written; every row against the oracle in tests/test_gpu_mac_regimes.py.)
 // The accumulate is element-wise on slots and only treats slot 0 specially: unchanged.
 //
-// Shape of the kernels (what was measured on the way: profiles/r04s_quad16_ab_v*.txt):
+// Shape of the kernels (what was measured on the way: profiles/r04s_quad16_ab_v*.txt, profiles/HISTORY.md section 5.3):
 //  - a window's samples are read ONCE and the inputs of all four transforms held in registers (128), the inverse keeps 64 partial
 //    sums across its four transforms: two waves per SIMD (256 registers), not the three of the 8192-point split kernels;
 //  - what the lower occupancy would expose is covered inside the workgroup: every barrier of the transforms waits for LDS traffic
 //    only (block_barrier), so stores and the requests for the NEXT tile / IR partition stay in flight across them;
-//  - both kernels issue 63-72 % of the VALU instructions the chip can (SQ_INSTS_VALU, profiles/r04t_valu_floor.txt) -- like the
-//    8192-point split kernels they are bound by instruction issue + the LDS exchanges between passes, not by HBM.
+//  - both kernels use about a third of the chip's VALU issue slots (SQ_INSTS_VALU x 2 cycles per wave64 instruction on a SIMD-32,
+//    profiles/pmc_traffic.json) and move their bytes at 5.1-5.3 TB/s: memory-side kernels, like the 8192-point split kernels.
 #pragma once
 #include <hip/hip_runtime.h>
 

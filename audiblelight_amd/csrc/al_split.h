@@ -11,7 +11,7 @@
 // B-point FFT: half the LDS per workgroup (35 KB instead of 68 KB at B = 8192: four resident workgroups per CU instead
 // of two), three passes of 16 instead of 32 x 16 x 16.  The odd half needs no real-FFT packing step at all.
 // Inverse: w2 = (s - d) / 2 with s = irFFT_B(even half), d from u = iFFT_{B/2}(U) * e^{+i pi n'/B}: the alias-free half
-// that overlap-save keeps (checked against the one-transform form in tests; formulas: DESIGN.md section 5).
+// that overlap-save keeps (checked against the one-transform form in tests; formulas: DESIGN.md section 5, "Split layout").
 #pragma once
 #include <hip/hip_runtime.h>
 

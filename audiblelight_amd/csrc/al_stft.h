@@ -1,7 +1,8 @@
 // The reference's STFT-domain intermediates of the moving-source path (audiblelight/synthesize.py:109-145 `stft`,
 // :184-252 `perform_time_variant_convolution`, :255-274 `istft_overlap_synthesis`) as device kernels, so the public
-// functions of the same names exist with the reference's signatures.  The product render path does NOT use them: it
-// evaluates the identical result in the envelope form; these are O(frames^2) like the reference.
+// functions of the same names exist with the reference's signatures.  The product render path evaluates the identical result in
+// the envelope form for the default STFT geometry and its multiples and chains these three on device
+// buffers for every other geometry (audiblelight_amd/synthesize.py::_render_moving_general); they are O(frames^2) like the reference.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -228,8 +228,10 @@ def cpu_workers_sweep(args):
                 rec = cpu_baseline_all_cores(args.config, args.scale, n, how, cfg["E"], cfg["E"] * cfg["N"], max_events=events,
                                              keep_padded=padded)
             finally:
-                if thp:
-                    os.environ.pop("GLIBC_TUNABLES", None) if saved is None else os.environ.__setitem__("GLIBC_TUNABLES", saved)
+                if thp and saved is None:
+                    os.environ.pop("GLIBC_TUNABLES", None)
+                elif thp:
+                    os.environ["GLIBC_TUNABLES"] = saved
             points.append({"workers": n, "padded_copies": padded, "malloc_huge_pages": thp, "scene_seconds_per_s": rec["value"],
                            "seconds_per_scene_per_worker_min_max": rec["seconds_per_scene_per_core"], "wall_s": rec["wall_s_including_input_generation"],
                            "pressure": rec["pressure_avg10_before_after"]["after"], "sample": rec["sample"]})

@@ -165,7 +165,8 @@ def peak_normalize_rows_device(renderer, dev, rows: int, cols: int) -> None:
     """Per-channel ``ch / max(|ch| + tiny)`` in place (reference ambience.py:211-214)."""
     r = renderer
     stats = r.mem.download(r.row_stats(dev, rows, cols)).reshape(-1, 4)[:rows]
-    scale = (1.0 / (stats[:, 1] + tiny(np.float64(0)))).astype(np.float32)
+    # a silent channel: 1 / tiny does not fit float32 and inf * 0 is NaN where the reference keeps zeros; saturated, FLT_MAX * 0 = 0
+    scale = np.minimum(1.0 / (stats[:, 1] + tiny(np.float64(0))), np.finfo(np.float32).max).astype(np.float32)
     r.lib.call("al_scale_matrix_rows", r.mem.ptr(dev), rows, cols, r.mem.ptr(r.mem.upload(scale)), r.mem.stream())
     r.mem.synchronize()
 

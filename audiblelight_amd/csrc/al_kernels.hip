@@ -32,14 +32,29 @@ __global__ void k_twiddle_init(float2 *tw, int m) {
   }
 }
 
+// A float64 scalar as the float32 the kernels multiply samples by, kept FINITE.  The reference forms these scalars in float64 --
+// 1 / tiny = 4.5e307 for an all-zero IR or clip, 10^(dB/20) / tiny for a silent render -- and multiplies ZEROS by them: silence
+// stays silence.  As float32 they would be +-inf and inf * 0 = NaN, so they saturate at +-FLT_MAX (FLT_MAX * 0 = 0).
+__device__ __forceinline__ float finite_f32(double v) {
+  return (float)fmin(fmax(v, -3.4028234663852886e38), 3.4028234663852886e38);
+}
+
 // ------------------------------------------------------------------ 2. emitter gains (normalize_irs)
 // one wave per emitter: g = 1 / mean_c( sqrt(sum_t h^2) + tiny(float64) )   (synthesize.py:425-428)
 // mode 0: g (single GPU); 1: emitter_gain[n] := sum over THIS rank's capsules of the norms (to be all-reduced);
 // 2: emitter_gain[n] := total_capsules / emitter_gain[n] (the reduced sum), for capsule-sharded scenes
+// An IR whose gain would not fit float32 (mean norm below 3e-39: every capsule's IR all zeros, or float32 denormals) gets gain 0:
+// the reference divides its zeros by tiny and keeps zeros; a saturated gain would overflow the signal spectra it multiplies.
+__device__ __forceinline__ float emitter_gain_of(double capsules, double norm_sum) {
+  const double g = capsules / norm_sum;
+  return g <= 3.4028234663852886e38 ? (float)g : 0.0f;
+}
+
 __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b, int mode, int total_capsules) {
   const int n = b.emitter0 + blockIdx.x, lane = threadIdx.x;
   if (mode == 2) {
-    if (lane == 0) b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)total_capsules / (double)b.emitter_gain[n]);
+    if (lane == 0)
+      b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : emitter_gain_of((double)total_capsules, (double)b.emitter_gain[n]);
     return;
   }
   double acc = 0.0;
@@ -53,7 +68,7 @@ __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b, int mode, int 
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if (lane == 0) {
     if (mode == 1) b.emitter_gain[n] = (float)acc;
-    else b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : (float)((double)b.n_capsules / acc);
+    else b.emitter_gain[n] = (b.flags & AL_FLAG_NO_IR_NORM) ? 1.0f : emitter_gain_of((double)b.n_capsules, acc);
   }
 }
 
@@ -753,7 +768,8 @@ __global__ __launch_bounds__(64) void k_event_levels(al_batch b, int mode, int t
     o[1] = (double)mx;
     o[2] = bad;
     o[3] = s2;
-    b.event_scale[e] = (float)(s1 * s2);
+    // a silent render (sum|x| = 0: zero clip or zero IRs) has s2 = 10^(dB/20) / tiny: the reference multiplies its zeros by it
+    b.event_scale[e] = finite_f32(s1 * s2);
   }
 }
 
@@ -846,7 +862,7 @@ __global__ __launch_bounds__(256) void k_scale(float *x, int64_t n, const float 
 }
 
 __global__ __launch_bounds__(256) void k_scale_d(float *x, int64_t n, const double *scale) {
-  const float s = (float)*scale;
+  const float s = finite_f32(*scale);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] *= s;
 }
 
@@ -884,7 +900,7 @@ __global__ __launch_bounds__(64) void k_ambience_scales(const double *__restrict
   const double mult = pow(10.0, (double)ref_db / 20.0) / (mean_abs + 2.2250738585072014e-308);
   for (int c = lane; c < rows; c += 64) {
     const double inv = normalize ? 1.0 / (stats[4 * c + 1] + 2.2250738585072014e-308) : 1.0;
-    scales[c] = (float)(normalize == 2 ? inv : mult * inv);   // 2: the peak normalisation alone
+    scales[c] = finite_f32(normalize == 2 ? inv : mult * inv);   // 2: the peak normalisation alone; a silent channel stays silent
   }
 }
 
@@ -1055,7 +1071,7 @@ __device__ __forceinline__ float peak_scale_of(const float *__restrict__ x, int6
   float mx = 0.f, z0 = 0.f, z1 = 0.f;
   for (int64_t i = threadIdx.x; i < n; i += 1024) mx = fmaxf(mx, fabsf(x[i]));
   block_reduce3(z0, mx, z1, red, threadIdx.x, 1024);
-  return s / (fabsf(s) * mx + 1.17549435e-38f);
+  return finite_f32((double)s / ((double)fabsf(s) * (double)mx + 1.17549435e-38));   // a silent clip under a gain of +12 dB or more: finite
 }
 
 // mode[e] 0: clip_scale[e] = prescale[e]; 1: the peak-normalising scale of clip e (events table gives offset / length)

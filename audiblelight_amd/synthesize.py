@@ -263,7 +263,8 @@ def normalize_irs(irs: np.ndarray) -> np.ndarray:
     stats = r.mem.download(r.row_stats(dev, flat.shape[0], cols)).reshape(-1, 4)[: flat.shape[0]]
     e = np.sqrt(stats[:, 3]).reshape(-1, rows)
     e = e + tiny(e)
-    scale = np.repeat(1.0 / e.mean(axis=1), rows).astype(np.float32)
+    # as float32 a 1 / tiny (all-zero rows: the reference keeps zeros) would be inf and inf * 0 = NaN: saturate, FLT_MAX * 0 = 0
+    scale = np.repeat(np.minimum(1.0 / e.mean(axis=1), np.finfo(np.float32).max), rows).astype(np.float32)
     s_dev = r.mem.upload(scale)
     for r0 in range(0, flat.shape[0], 65535):  # one launch per 65535 rows (grid.y limit)
         nr = min(65535, flat.shape[0] - r0)
@@ -677,7 +678,7 @@ def _ambience_on_device(r: engine.Renderer, ambience, shape):
         raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {tuple(ambience.device_shape)}.")
     n = shape[0] * shape[1]
     stats = r.mem.download(r.row_stats(dev, 1, n)).reshape(-1, 4)
-    mult = db_to_multiplier(ambience.ref_db, stats[0, 0] / n)
+    mult = min(db_to_multiplier(ambience.ref_db, stats[0, 0] / n), float(np.finfo(np.float32).max))   # silent noise: finite x 0 = 0
     return dev, r.mem.upload(np.full(shape[0], mult, dtype=np.float32))
 
 

@@ -218,6 +218,7 @@ def main():
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays")
     stft_vectors(syn)
     geometry_vectors(syn)
+    edge_vectors(syn)
 
 
 def stft_vectors(syn):
@@ -279,6 +280,34 @@ def geometry_vectors(syn):
     path = os.path.join(HERE, "reference_geometry_vectors.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays; refused by the reference:", refused)
+
+
+def edge_vectors(syn):
+    """G15: degenerate events as the REFERENCE renders them (its float64 arithmetic multiplies zeros by 1 / tiny and by
+    10^(dB/20) / tiny and keeps zeros): snr = 0 (silence), a negative snr (polarity flips), an all-zero IR, an all-zero clip, a
+    moving event with one all-zero IR among its emitters, a dry render of an all-zero clip.  A file and seed of its own."""
+    rng = np.random.default_rng(20261005)
+    sr, n_caps = 8000, 2
+    a = make_clip(rng, 1500)
+    h = make_irs(rng, n_caps, 1, 400)
+    h3 = make_irs(rng, n_caps, 3, 400)
+    h3[:, 1, :] = 0.0
+    out = dict(g15_audio=a, g15_irs=h.astype(np.float32), g15_irs_moving=h3.astype(np.float32))
+    cases = {"snr0": (a, h, 0.0, False, {}), "snr_neg": (a, h, -4.0, False, {}), "zero_ir": (a, np.zeros_like(h), 9.0, False, {}),
+             "zero_clip": (np.zeros_like(a), h, 9.0, False, {}), "moving_one_zero_ir": (a, h3, 7.0, True, {}),
+             "zero_clip_dry": (np.zeros_like(a), h, 9.0, False, dict(ref_ir_channel=0, direct_path_time_ms=[2, 20]))}
+    for tag, (clip, irs, snr, moving, kw) in cases.items():
+        ev = FakeEvent(tag, clip, irs.shape[1], snr=snr, sr=sr, is_moving=moving, **kw)
+        with np.errstate(all="ignore"):
+            syn.render_event_audio(ev, irs, "mic000", ref_db=-65)
+        out[f"g15_{tag}_spatial"] = ev.spatial_audio["mic000"]
+        if kw:
+            out[f"g15_{tag}_dry"] = ev._spatial_audio_dry["mic000"]
+    out["g15_snrs"] = np.array([0.0, -4.0, 9.0, 9.0, 7.0, 9.0])
+    path = os.path.join(HERE, "reference_edge_vectors.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB,", len(out), "arrays;",
+          {k: (bool(np.isfinite(v).all()), float(np.abs(v).max())) for k, v in out.items() if k.endswith(("_spatial", "_dry"))})
 
 
 if __name__ == "__main__":

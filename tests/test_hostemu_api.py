@@ -432,6 +432,53 @@ def test_moving_events_under_other_stft_geometries():
     assert r is syn.get_renderer()
 
 
+def test_degenerate_events_render_like_the_reference():
+    """Silence stays silence (G15: the reference's own renders of degenerate events): snr = 0, a negative snr, an all-zero IR, an
+    all-zero clip, a moving event with one all-zero IR among its emitters, the dry render of an all-zero clip.  The reference forms
+    1 / tiny and 10^(dB/20) / tiny in float64 and multiplies zeros by them; the device keeps every such scalar finite in float32
+    (csrc/al_kernels.hip: finite_f32, emitter_gain_of).  Then the same events in ONE scene with a silent ambience and a silent clip
+    under a +12 dB gain: the mix is finite and equals the oracle's."""
+    import os
+
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "reference_edge_vectors.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    a, h, h3 = z["g15_audio"], z["g15_irs"], z["g15_irs_moving"]
+    cases = {"snr0": (a, h, 0.0, {}), "snr_neg": (a, h, -4.0, {}), "zero_ir": (a, np.zeros_like(h), 9.0, {}),
+             "zero_clip": (np.zeros_like(a), h, 9.0, {}), "moving_one_zero_ir": (a, h3, 7.0, dict(n_emitters=3, is_moving=True)),
+             "zero_clip_dry": (np.zeros_like(a), h, 9.0, dict(ref_ir_channel=0, direct_path_time_ms=[2, 20]))}
+    for tag, (clip, irs, snr, kw) in cases.items():
+        ev = core.Event(tag, clip, 8000, snr=snr, **kw)
+        ev.audio = np.asarray(clip, dtype=np.float32)       # the finished clip, as the golden's event hands it over (no peak normalisation of zeros)
+        syn.render_event_audio(ev, irs, "mic000", ref_db=-65)
+        got, want = ev.spatial_audio["mic000"], z[f"g15_{tag}_spatial"]
+        assert np.isfinite(got).all() and got.shape == want.shape, tag
+        if np.abs(want).max() == 0:
+            assert np.abs(got).max() == 0, tag
+        else:
+            assert_parity(got, want, TOL, what=tag)
+        if "ref_ir_channel" in kw:
+            dry = ev._spatial_audio_dry["mic000"]
+            assert np.isfinite(dry).all() and np.abs(dry).max() == 0
+    # one scene: a normal event, a silent clip under Gain(+12 dB) (folded scalar: 4 / tiny32 would overflow float32), an event
+    # whose IR is all zeros, and an ambience of silence; scene.audio is finite and equals the oracle's mix of the one audible event
+    rng = np.random.default_rng(15)
+    sr, C, L = 8000, 2, 400
+    irs = np.concatenate([h, h, np.zeros_like(h)], axis=1)
+    scene = core.Scene(0.5, core.StaticIRState({"mic000": irs}), sample_rate=sr, ref_db=-65)
+    scene.add_event(core.Event("loud", a, sr, snr=10.0, scene_start=0.05))
+    scene.add_event(core.Event("silent", np.zeros(1200, np.float32), sr, snr=10.0, scene_start=0.1, augmentations=[aug.Gain(sr, gain_db=12.5)]))
+    scene.add_event(core.Event("deaf", a[:1000], sr, snr=10.0, scene_start=0.2))
+    from audiblelight_amd import ambience as amb
+    scene.add_ambience(amb.Ambience(C, 0.5, alias="hush", clip=np.zeros((1, 4000), np.float32), ref_db=-60, sample_rate=sr))
+    got = scene.generate()["mic000"]
+    assert np.isfinite(got).all()
+    want = orc.render_event(orc.peak_normalise_clip(a), h.astype(np.float64), 10.0, ref_db=-65, sr=sr)["spatial"]
+    ref = orc.mix_scene([want], [(0.05, 0.05 + len(a) / sr)], 0.5, sr, keep_padded=False)["scene"]
+    assert_parity(got, ref, TOL)
+    for ev in scene.events.values():
+        assert np.isfinite(ev.spatial_audio["mic000"]).all()
+
+
 def test_fx_chain_stays_on_device_and_scalars_fold():
     """BASELINE configs[4]'s "gain/polarity augmentations fused" through the PRODUCT classes: events built with
     ``augmentations=[Gain, Invert]`` render to what the oracle gives for peak_normalise(invert(gain(raw))) with no FX

@@ -246,3 +246,26 @@ def test_g14_other_stft_geometries():
     # what the reference refuses: frames longer than the overlap-add buffer allows (fft > 2*hop + win) and win < hop
     for fft_size, win, hop in z["g14_refused"].tolist():
         assert fft_size > 2 * hop + win or win < hop
+
+
+def test_g15_degenerate_events():
+    """G15 (tests/golden/make_golden.py::edge_vectors): snr = 0, a negative snr, an all-zero IR, an all-zero clip, a moving event with
+    one all-zero IR, the dry render of an all-zero clip -- the reference keeps silence silent (zeros times 1 / tiny stay zeros in
+    float64) and so does the oracle."""
+    with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_edge_vectors.npz")) as z:
+        z = {k: z[k] for k in z.files}
+    a, h, h3 = z["g15_audio"], z["g15_irs"].astype(np.float64), z["g15_irs_moving"].astype(np.float64)
+    cases = {"snr0": (a, h, 0.0, False, {}), "snr_neg": (a, h, -4.0, False, {}), "zero_ir": (a, np.zeros_like(h), 9.0, False, {}),
+             "zero_clip": (np.zeros_like(a), h, 9.0, False, {}), "moving_one_zero_ir": (a, h3, 7.0, True, {}),
+             "zero_clip_dry": (np.zeros_like(a), h, 9.0, False, dict(ref_ir_channel=0, direct_path_time_ms=[2, 20]))}
+    for tag, (clip, irs, snr, moving, kw) in cases.items():
+        with np.errstate(all="ignore"):
+            res = orc.render_event(clip, irs, snr, ref_db=-65, is_moving=moving, duration=len(clip) / 8000, sr=8000, **kw)
+        want = z[f"g15_{tag}_spatial"]
+        assert np.isfinite(res["spatial"]).all() and res["spatial"].shape == want.shape
+        if np.abs(want).max() == 0:
+            assert np.abs(res["spatial"]).max() == 0, tag
+        else:
+            assert rel_rms(res["spatial"], want) < 1e-10, tag
+        if kw:
+            assert np.isfinite(res["dry"]).all() and np.abs(res["dry"]).max() == 0 and np.abs(z[f"g15_{tag}_dry"]).max() == 0

@@ -139,14 +139,17 @@ typedef struct {
   const al_stream *streams; /* S entries */
 
   float *ir_energy;  /* workspace: n_emitters * C * P partial sums of ir^2 */
-  float *emitter_gain; /* workspace/out: n_emitters, 1 / mean_c ||ir||  (normalize_irs, synthesize.py:404-428) */
+  float *emitter_gain; /* workspace/out: n_emitters, 1 / mean_c ||ir||  (normalize_irs, synthesize.py:404-428); 0 for an emitter whose
+                          IRs are all zeros (the reference divides zeros by tiny and keeps zeros) */
   float *hspec;      /* workspace: n_emitters * C * P blocks of B complex, [n - emitter0][c][p] */
   float *xspec;      /* workspace: sum(n_j) blocks of B complex */
   float *yspec;      /* workspace: sum(C * n_blocks) blocks of B complex */
   float *spatial;    /* out: per event (C, len) float32, UNSCALED convolution truncated/padded to len */
   float *partials;   /* workspace: 4 floats per (event, c, k): sum|x|, max|x|, non-finite count, pad */
   double *event_stats; /* out: 4 doubles per event: sum|x|, max|x|, non-finite count, total scale */
-  float *event_scale;  /* out: per event multiplier = apply_snr o db_to_multiplier (synthesize.py:594-599) */
+  float *event_scale;  /* out: per event multiplier = apply_snr o db_to_multiplier (synthesize.py:594-599), saturated at +-FLT_MAX:
+                          a silent render (all-zero clip or IRs) has 10^(dB/20) / tiny here, which the reference multiplies its
+                          zeros by in float64 -- silence stays silence, never inf * 0 */
   const float *clip_scale; /* optional (NULL = 1): per event scalar applied to the clip on top of al_stream.gain; written on
                               the device by al_clip_scales (peak normalisation + folded Gain/Invert, event.py:529-536), so
                               the clip's peak never travels to the host.  Indexed globally like event_scale. */

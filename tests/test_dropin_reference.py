@@ -70,3 +70,16 @@ def test_install_rebinds_what_scene_generate_imports(reference_synthesize, golde
         ours.set_renderer(None)
     for n in dropin.REPLACED:
         assert getattr(ref_syn, n) is originals[n]
+
+
+def test_differential_fuzz_against_the_reference():
+    """tests/golden/differential_fuzz.py on a handful of seeds: random scenes (static / moving / tiled events, snr 0 and negative,
+    silent clips, all-zero IRs, events off the scene's ends, coloured ambiences, dry renders) rendered by the REFERENCE's own
+    functions and by this package's over the host-emulated kernels, every array compared.  In a process of its own: the reference
+    tree has a `tests` package too.  (600+ seeds: profiles/r05l_differential_fuzz.txt.)"""
+    import subprocess
+
+    script = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "differential_fuzz.py")
+    res = subprocess.run([sys.executable, script, "0", "25"], capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-2000:]
+    assert "0 outside 1e-4" in res.stdout

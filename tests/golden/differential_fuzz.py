@@ -99,6 +99,28 @@ def fx_and_noise_cases(seed, ref_aug, ref_amb, our_aug, our_amb):
     return out
 
 
+SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(11) for b in range(4) for c in range(3) for d in range(2)
+                 if 32 <= 2 ** a * 3 ** b * 5 ** c * 7 ** d <= 1024})
+
+
+def geometry_case(seed, ref_syn, ours):
+    """One moving event under a random STFT geometry the reference accepts (win >= hop, fft <= 2*hop + win; fft a product of 2, 3, 5, 7:
+    this package's own limit), rendered by the reference's render_event_audio and by ours (synthesize.py:507-608,277-310)."""
+    rng = np.random.default_rng(85_000 + seed)
+    hop = int(rng.integers(16, 200))
+    win = int(rng.integers(hop, 3 * hop + 1))
+    ok = [f for f in SMOOTH if f <= 2 * hop + win]
+    fft = int(rng.choice(ok[-10:])) if rng.random() < 0.7 else int(rng.choice(ok))
+    n_irs, n_caps, sr = int(rng.integers(2, 6)), int(rng.integers(1, 4)), 8000
+    a, h = mg.make_clip(rng, int(rng.integers(1500, 6000))), mg.make_irs(rng, n_caps, n_irs, int(rng.integers(100, 1200)))
+    snr = float(rng.uniform(5, 30))
+    ev_a = mg.FakeEvent("g", a, n_irs, snr, sr, is_moving=True)
+    ev_b = mg.FakeEvent("g", a, n_irs, snr, sr, is_moving=True)
+    ref_syn.render_event_audio(ev_a, h, "mic000", ref_db=-60, fft_size=fft, win_size=win, hop_size=hop)
+    ours.render_event_audio(ev_b, h, "mic000", ref_db=-60, fft_size=fft, win_size=win, hop_size=hop)
+    return f"moving event, fft/win/hop = {fft}/{win}/{hop}", ev_b.spatial_audio["mic000"], ev_a.spatial_audio["mic000"]
+
+
 def errors(got, ref):
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     if got.shape != ref.shape:
@@ -157,7 +179,7 @@ def main():
     ref_aug.librosa.util.frame = _frame           # librosa is absent: its documented framing, as in make_fx_golden.py
     n_fx = 0
     for seed in range(first, last):
-        for what, got, ref in fx_and_noise_cases(seed, ref_aug, ref_amb, our_aug, our_amb):
+        for what, got, ref in fx_and_noise_cases(seed, ref_aug, ref_amb, our_aug, our_amb) + [geometry_case(seed, ref_syn, ours)]:
             rms, mx = errors(got, ref)
             n_cmp, n_fx = n_cmp + 1, n_fx + 1
             if max(rms, mx) > worst[0]:
@@ -165,7 +187,8 @@ def main():
             if rms > 1e-4 or mx > 1e-4:
                 bad.append((seed, what, rms, mx))
     ours.set_renderer(None)
-    print(f"{n_fx} of the arrays are FX / coloured-noise outputs (Fade, Invert, Reverse, TimeWarp*, powerlaw_psd_gaussian)")
+    print(f"{n_fx} of the arrays are FX / coloured-noise outputs (Fade, Invert, Reverse, TimeWarp*, powerlaw_psd_gaussian) and moving events "
+          f"under random STFT geometries")
     print(f"seeds {first}..{last - 1}: {n_cmp} arrays compared with the reference's own ({n_silent} of them silent), {len(bad)} outside 1e-4; "
           f"worst error {worst[0]:.2e} at {worst[1]}")
     for item in bad[:20]:

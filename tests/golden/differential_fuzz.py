@@ -44,6 +44,12 @@ def random_scene(seed, amb_mod):
             h[:, int(rng.integers(0, ne)), :] = 0.0                  # an all-zero IR (one emitter of a moving event, or the static one)
         snr = float(rng.choice([0.0, -float(rng.uniform(1, 10)), float(rng.uniform(5, 30)), float(rng.uniform(5, 30))]))
         start = float(rng.uniform(-0.05, dur * 1.02))               # some start before 0, some at or beyond the scene's end
+        if seed >= 100_000:     # the adversarial range: clips that are not peak-normalised, IRs far from unit scale, slots on half samples
+            a = (a * float(rng.choice([1.0, 1.0, 1e-6, 1e-20, 3e5]))).astype(np.float32)
+            h = h * float(rng.choice([1.0, 1.0, 1e-8, 1e4]))
+            h = h.astype(np.float32).astype(np.float64)
+            if rng.random() < 0.5:
+                start = (int(rng.integers(0, int(dur * sr))) + 0.5) / sr     # round-half-even on both slot ends (synthesize.py:361-362)
         # (no dry render for snr = 0: the reference scales it by db_to_multiplier(., mean|0|) = 10^(dB/20) / tiny, i.e. to 1e305 in
         # float64 -- its own output is overflow-scale garbage there, and nothing a float32 path could or should reproduce)
         dry = ne == 1 and snr != 0.0 and rng.random() < 0.25

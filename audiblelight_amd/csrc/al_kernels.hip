@@ -36,6 +36,7 @@ __global__ void k_twiddle_init(float2 *tw, int m) {
 // 1 / tiny = 4.5e307 for an all-zero IR or clip, 10^(dB/20) / tiny for a silent render -- and multiplies ZEROS by them: silence
 // stays silence.  As float32 they would be +-inf and inf * 0 = NaN, so they saturate at +-FLT_MAX (FLT_MAX * 0 = 0).
 __device__ __forceinline__ float finite_f32(double v) {
+  if (v != v) return (float)v;     // NaN stays NaN: non-finite INPUT must still fail the finite check (librosa.util.valid_audio)
   return (float)fmin(fmax(v, -3.4028234663852886e38), 3.4028234663852886e38);
 }
 
@@ -47,7 +48,7 @@ __device__ __forceinline__ float finite_f32(double v) {
 // the reference divides its zeros by tiny and keeps zeros; a saturated gain would overflow the signal spectra it multiplies.
 __device__ __forceinline__ float emitter_gain_of(double capsules, double norm_sum) {
   const double g = capsules / norm_sum;
-  return g <= 3.4028234663852886e38 ? (float)g : 0.0f;
+  return (g <= 3.4028234663852886e38 || g != g) ? (float)g : 0.0f;   // NaN (a NaN in the IR) stays NaN and fails the finite check
 }
 
 __global__ __launch_bounds__(64) void k_emitter_gains(al_batch b, int mode, int total_capsules) {

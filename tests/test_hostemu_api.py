@@ -459,6 +459,17 @@ def test_degenerate_events_render_like_the_reference():
         if "ref_ir_channel" in kw:
             dry = ev._spatial_audio_dry["mic000"]
             assert np.isfinite(dry).all() and np.abs(dry).max() == 0
+    # ... while non-finite INPUT still fails the reference's finite check (librosa.util.valid_audio of the render, synthesize.py:603):
+    # the saturating scalars above must not launder a NaN or an Inf in an IR into silence
+    for poison in (np.nan, np.inf):
+        bad_ir = h.copy()
+        bad_ir[1, 0, 17] = poison
+        with pytest.raises(ValueError, match="not finite"):
+            syn.render_event_audio(core.Event("poisoned", a, 8000, snr=9.0), bad_ir, "mic000", ref_db=-65)
+        bad3 = h3.copy()
+        bad3[0, 2, 5] = poison
+        with pytest.raises(ValueError, match="not finite"):
+            syn.render_event_audio(core.Event("poisoned", a, 8000, snr=9.0, n_emitters=3, is_moving=True), bad3, "mic000", ref_db=-65)
     # one scene: a normal event, a silent clip under Gain(+12 dB) (folded scalar: 4 / tiny32 would overflow float32), an event
     # whose IR is all zeros, and an ambience of silence; scene.audio is finite and equals the oracle's mix of the one audible event
     rng = np.random.default_rng(15)

@@ -125,6 +125,24 @@ def _pressure():
     return out
 
 
+def committed_workers_sweep(config):
+    """The worker-count sweep of the all-cores leg as measured ONCE on a pool box (bench.py --cpu-workers-sweep, committed under
+    profiles/): why this leg runs one process per CPU of the cgroup quota and not per visible core.  Not re-measured per run."""
+    path = os.path.join(ROOT, "profiles", "r05b_cpu_workers_sweep.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("config") != config:
+        return None
+    return {"source": "profiles/r05b_cpu_workers_sweep.json (one pool box, 6 of 64 events per scene, not re-measured in this run)",
+            "cpu_quota_there": rec["cpu_quota"]["cpus_allowed_by_quota"], "knee_workers": rec["knee_workers"],
+            "scene_seconds_per_s_by_workers": {str(p_["workers"]): round(p_["scene_seconds_per_s"], 1) for p_ in rec["workers_sweep"]
+                                               if p_["padded_copies"] and not p_["malloc_huge_pages"]},
+            "without_padded_copies": {str(p_["workers"]): round(p_["scene_seconds_per_s"], 1) for p_ in rec["workers_sweep"]
+                                      if not p_["padded_copies"]}}
+
+
 def _cpu_scene_worker(job):
     """ONE whole scene through the oracle in a worker process, the way the reference runs it (synthesize.py:613-677 then
     :314-401): every event rendered, added into the float32 scene buffer, and the reference's per-event full-scene padded copy
@@ -192,6 +210,7 @@ def cpu_baseline_all_cores(config, scale, workers, how, full_events, full_work, 
     per_scene_s = slowest * full_work / max(sample_work, 1)
     return dict(value=workers * duration / per_scene_s, unit="scene-seconds/s", cores=workers, host_cpus=os.cpu_count(), kind="port",
                 cpu_model=cpu_model(), core_count_from=how, extrapolated=extrapolated, cpu_quota=cpu_quota(),
+                workers_sweep=committed_workers_sweep(config),
                 pressure_avg10_before_after={"before": before, "after": _pressure()}, per_event_padded_copies=bool(keep_padded),
                 seconds_per_scene_per_core=[round(min(t for t, _ in results), 2), round(slowest, 2)],
                 wall_s_including_input_generation=round(wall_with_inputs, 1),

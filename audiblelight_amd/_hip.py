@@ -118,6 +118,7 @@ SYMBOLS = {
     "al_spectral_mac": (ct.c_int, [ct.POINTER(AlBatch), _S]),
     "al_spectral_mac_variant": (ct.c_int, [ct.POINTER(AlBatch), ct.POINTER(ct.c_int32), ct.POINTER(ct.c_int32)]),
     "al_plan_last_error": (ct.c_char_p, []),
+    "al_plan_abi_version": (ct.c_int, []),
     "al_choose_log2_block": (ct.c_int32, [ct.c_int32, ct.c_int32]),
     "al_stft_frame_count": (ct.c_int32, [ct.c_int64, ct.c_int32]),
     "al_interpolation_rows": (ct.c_int32, [ct.c_int32, ct.c_double, ct.c_double, ct.c_int32]),
@@ -222,3 +223,49 @@ def get_library() -> Library:
     if _default is None:
         _default = Library()
     return _default
+
+
+# ----------------------------------------------------------------------------- the planner alone
+# csrc/al_plan.cpp is plain C++ with no device call: build() also links it into a library of its own, so that planning (tables,
+# workspace sizes, block size, dispatch flags) runs on a host without ROCm, without importing torch, and before any GPU is
+# touched.  A Renderer plans with ITS library (the full one exports the same symbols); everything else uses this one.
+DEFAULT_PLANNER = os.path.join(_HERE, "csrc", "libaudiblelight_plan.so")
+PLANNER_SYMBOLS = ("al_plan_last_error", "al_plan_abi_version", "al_choose_log2_block", "al_stft_frame_count", "al_interpolation_rows",
+                   "al_interpolation_matrix", "al_plan_create", "al_plan_destroy", "al_plan_get_info", "al_plan_events",
+                   "al_plan_streams", "al_plan_wtab", "al_plan_audio_offsets", "al_workspace_bytes", "al_plan_chunk",
+                   "al_plan_emitter_parts", "al_plan_batch_flags", "al_plan_mixdown", "al_mix_plan_destroy", "al_mix_plan_get")
+
+
+class PlannerLibrary:
+    """The host-side planner behind the C ABI, loaded from the planner-only library; same ``call`` contract as ``Library``."""
+
+    def __init__(self, path: Optional[str] = None):
+        path = path or os.environ.get("AUDIBLELIGHT_PLAN_LIB") or DEFAULT_PLANNER
+        if not os.path.exists(path):
+            raise RuntimeError(f"audiblelight_amd: planner library not found at {path}. Build it with "
+                               f"`python -c 'import __graft_entry__ as g; g.build()'`.")
+        self.path = path
+        self._dll = ct.CDLL(path)
+        for name in PLANNER_SYMBOLS:
+            fn = getattr(self._dll, name)
+            fn.restype, fn.argtypes = SYMBOLS[name]
+            setattr(self, "_" + name, fn)
+        built = self._al_plan_abi_version()
+        if built != ABI_VERSION:
+            raise RuntimeError(f"audiblelight_amd: {path} implements C-ABI version {built}, this package binds version {ABI_VERSION}: rebuild it")
+
+    def call(self, name: str, *args):
+        rc = getattr(self, "_" + name)(*args)
+        if isinstance(rc, int) and rc < 0 and SYMBOLS[name][0] is ct.c_int:
+            raise HipError(f"{name} failed ({rc}): {(self._al_plan_last_error() or b'').decode()}")
+        return rc
+
+
+_planner: Optional[PlannerLibrary] = None
+
+
+def get_planner() -> PlannerLibrary:
+    global _planner
+    if _planner is None:
+        _planner = PlannerLibrary()
+    return _planner

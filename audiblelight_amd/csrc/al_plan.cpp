@@ -58,6 +58,7 @@ struct al_mix_plan {
 extern "C" {
 
 const char *al_plan_last_error(void) { return g_plan_err; }
+int al_plan_abi_version(void) { return AL_ABI_VERSION; }   // the planner is also linked into a library of its own (no HIP): same check
 
 int32_t al_choose_log2_block(int32_t ir_len, int32_t max_clip) {
   // largest block that keeps two workgroups resident per CU (B = 8192), shrunk for short inputs so that the zero padding of

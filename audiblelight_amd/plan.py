@@ -23,8 +23,8 @@ from ._hip import EVENT_DTYPE, MAX_LOG2_BLOCK, MIN_LOG2_BLOCK, STREAM_DTYPE
 def _lib(lib=None):
     """The library a planning call goes through: the caller's (a Renderer built on its own Library -- host emulation, a
     sanitizer build, AUDIBLELIGHT_HIP_LIB -- plans with THAT library, whose al_plan_last_error is the one that holds the
-    message) or the process default."""
-    return lib if lib is not None else _hip.get_library()
+    message) or the planner-only library (csrc/al_plan.cpp linked alone: no HIP, no torch, no GPU needed to plan)."""
+    return lib if lib is not None else _hip.get_planner()
 
 
 def _copy(ptr, n, dtype):

@@ -406,6 +406,9 @@ typedef struct {            /* the al_batch fields of a chunk of consecutive eve
 } al_chunk;
 
 const char *al_plan_last_error(void);
+/* The planner is plain host code: it is exported by libaudiblelight_hip.so AND by libaudiblelight_plan.so (csrc/al_plan.cpp alone,
+ * no HIP dependency), for hosts that plan on a machine without ROCm; al_plan_abi_version() is what that library answers to. */
+int al_plan_abi_version(void);
 int32_t al_choose_log2_block(int32_t ir_len, int32_t max_clip);
 int32_t al_stft_frame_count(int64_t n_samples, int32_t hop);                          /* synthesize.py:123 */
 int32_t al_interpolation_rows(int32_t n_irs, double duration, double sample_rate, int32_t hop);

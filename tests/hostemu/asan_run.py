@@ -13,7 +13,8 @@ def setenv(name, value):     # the package parses its AL_* switches once per pro
 
 
 from tests import hostemu
-_hip._default = _hip.Library(sys.argv[1])     # the planner (csrc/al_plan.cpp) runs from the sanitized build too
+_hip._default = _hip.Library(sys.argv[1])
+_hip._planner = _hip._default                  # the planner (csrc/al_plan.cpp) runs from the sanitized build too
 r = engine.Renderer(lib=_hip._default, memory=hostemu.NumpyMemory())
 rng = np.random.default_rng(0)
 C, L, sr = 3, 700, 8000

@@ -618,3 +618,37 @@ def test_dispatch_policy_lives_behind_the_c_abi():
         import ctypes as ct
 
         lib.call("al_plan_batch_flags", pl._c_plan(), ct.byref(ch), ct.byref(ct.c_int32()))
+
+
+def test_planning_needs_neither_rocm_nor_torch():
+    """csrc/al_plan.cpp is linked into a library of its own (libaudiblelight_plan.so: plain C++, no HIP): planning -- tables, workspace
+    sizes, block size, dispatch flags, mixdown slots -- runs in a process that never loads the HIP library, never imports torch and
+    could not find the GPU library if it tried; and it gives the tables the full library gives."""
+    import subprocess
+    import sys
+
+    code = r'''
+import os, sys
+os.environ["AUDIBLELIGHT_HIP_LIB"] = "/nonexistent/libaudiblelight_hip.so"
+from audiblelight_amd import _hip, plan as planning
+specs = [planning.EventSpec(n_samples=50_000, n_emitters=1, snr=10.0, emitter0=0),
+         planning.EventSpec(n_samples=70_000, n_emitters=4, snr=12.0, emitter0=1, is_moving=True, duration=70_000 / 48000.0)]
+pl = planning.plan_batch(specs, 3, 30_001, 48000.0)
+mp = planning.plan_mixdown([0.1, 0.5], [1.2, 2.0], [50_000, 70_000], [3, 3], pl.events["out_off"], [0, 1], 2.5, 48000.0, 3)
+assert len(pl.chunks(1)) == 2
+assert "torch" not in sys.modules and _hip._default is None and _hip.get_planner().path.endswith("libaudiblelight_plan.so")
+print(int(pl.events["yspec_base"][1]), pl.xspec_blocks, int(mp.tile_ptr[-1]), planning.stft_frame_count(1000), pl.log2_block, pl.batch_flags())
+'''
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert res.returncode == 0, res.stderr[-2000:]
+    from audiblelight_amd import plan as planning
+
+    specs = [planning.EventSpec(n_samples=50_000, n_emitters=1, snr=10.0, emitter0=0),
+             planning.EventSpec(n_samples=70_000, n_emitters=4, snr=12.0, emitter0=1, is_moving=True, duration=70_000 / 48000.0)]
+    full = planning.plan_batch(specs, 3, 30_001, 48000.0, lib=_hip.get_library())
+    mp = planning.plan_mixdown([0.1, 0.5], [1.2, 2.0], [50_000, 70_000], [3, 3], full.events["out_off"], [0, 1], 2.5, 48000.0, 3,
+                               lib=_hip.get_library())
+    assert res.stdout.split() == [str(int(full.events["yspec_base"][1])), str(full.xspec_blocks), str(int(mp.tile_ptr[-1])), "9",
+                                  str(full.log2_block), str(full.batch_flags())]
+    assert full.batch_flags() & _hip.FLAG_STATIC_MAC and not full.batch_flags() & _hip.FLAG_ONLY_STATIC

@@ -676,6 +676,12 @@ def _ambience_on_device(r: engine.Renderer, ambience, shape):
             dev = r.mem.upload(np.ascontiguousarray(host, dtype=np.float32).reshape(-1))
     elif tuple(ambience.device_shape) != tuple(shape):
         raise ValueError(f"Scene ambient noise does not match expected shape. Expected {tuple(shape)}, but got {tuple(ambience.device_shape)}.")
+    if shape[0] <= 1024:
+        # db_to_multiplier(ref_db, mean|noise|) from the per-channel statistics, on the stream: the host neither waits nor reads
+        scales = r.mem.empty(shape[0])
+        r.lib.call("al_ambience_scales", r.mem.ptr(r.row_stats(dev, shape[0], shape[1])), shape[0], shape[1], float(ambience.ref_db), 0,
+                   r.mem.ptr(scales), r.mem.stream())
+        return dev, scales
     n = shape[0] * shape[1]
     stats = r.mem.download(r.row_stats(dev, 1, n)).reshape(-1, 4)
     mult = min(db_to_multiplier(ambience.ref_db, stats[0, 0] / n), float(np.finfo(np.float32).max))   # silent noise: finite x 0 = 0

@@ -261,7 +261,7 @@ int64_t al_workspace_bytes(const al_plan *p) {
 // The al_batch fields of a run of consecutive events ("chunk") over the plan's global tables: a long scene is rendered as several
 // chunks that reuse ONE spectra workspace (al_batch.event0 / stream0 / emitter0 / *_block0).
 int al_plan_chunk(const al_plan *p, int32_t event0, int32_t n_events, al_chunk *out) {
-  if (!p || !out || event0 < 0 || n_events < 0 || event0 + n_events > (int32_t)p->events.size()) return plan_fail(AL_E_BADARG, "bad chunk range");
+  if (!p || !out || event0 < 0 || n_events < 0 || event0 > (int32_t)p->events.size() || n_events > (int32_t)p->events.size() - event0) return plan_fail(AL_E_BADARG, "bad chunk range");
   memset(out, 0, sizeof(*out));
   out->event0 = event0; out->n_events = n_events;
   if (n_events == 0) return AL_OK;
@@ -303,7 +303,7 @@ int al_plan_batch_flags(const al_plan *p, const al_chunk *chunk, int32_t *flags)
   int32_t e0 = 0, n = (int32_t)p->events.size();
   if (chunk) {
     e0 = chunk->event0; n = chunk->n_events;
-    if (e0 < 0 || n < 0 || e0 + n > (int32_t)p->events.size()) return plan_fail(AL_E_BADARG, "bad chunk range");
+    if (e0 < 0 || n < 0 || e0 > (int32_t)p->events.size() || n > (int32_t)p->events.size() - e0) return plan_fail(AL_E_BADARG, "bad chunk range");
   }
   int32_t f = 0;
   if (p->log2_block == 13) f |= AL_FLAG_SPLIT_SPECTRA;

@@ -554,6 +554,12 @@ def test_c_planner_edge_cases():
     ch = _hip.AlChunk()
     with pytest.raises(_hip.HipError, match="bad chunk range"):
         lib.call("al_plan_chunk", pl._c_plan(), 1, 5, ct.byref(ch))
+    flags = ct.c_int32(0)
+    for e0, n in ((1, 2**31 - 1), (2**31 - 1, 1), (3, 0), (-1, 1)):      # sums past INT32_MAX must not wrap into range
+        with pytest.raises(_hip.HipError, match="bad chunk range"):
+            lib.call("al_plan_chunk", pl._c_plan(), e0, n, ct.byref(ch))
+        with pytest.raises(_hip.HipError, match="bad chunk range"):
+            lib.call("al_plan_batch_flags", pl._c_plan(), ct.byref(_hip.AlChunk(event0=e0, n_events=n)), ct.byref(flags))
     lib.call("al_plan_chunk", pl._c_plan(), 1, 1, ct.byref(ch))          # a chunk of one tiled event: no spectra of its own
     assert (ch.n_emitters, ch.xspec_blocks, ch.yspec_blocks, ch.n_streams, ch.max_blocks) == (0, 0, 0, 1, 2)
     mix = planning.plan_mixdown([], [], [], [], [], [], 1.0, 8000, 2)

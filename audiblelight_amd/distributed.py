@@ -84,9 +84,13 @@ def _parse_cpulist(text: str) -> List[int]:
     return cpus
 
 
-def init_process_group(backend: Optional[str] = None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract)."""
+def init_process_group(backend: Optional[str] = None, timeout_s: Optional[float] = None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun contract).
+
+    ``timeout_s`` (default: AL_DIST_TIMEOUT_S, else 120 s) bounds every collective: a rank that dies leaves its siblings blocked
+    for that long instead of the backend's own default (RCCL: ten minutes)."""
     import os
+    from datetime import timedelta
 
     import torch
     import torch.distributed as dist
@@ -100,7 +104,9 @@ def init_process_group(backend: Optional[str] = None):
         local = int(os.environ.get("LOCAL_RANK", "0"))
         torch.cuda.set_device(local)
         kwargs["device_id"] = torch.device(f"cuda:{local}")
-    dist.init_process_group(backend, **kwargs)
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("AL_DIST_TIMEOUT_S", "120"))
+    dist.init_process_group(backend, timeout=timedelta(seconds=timeout_s), **kwargs)
     return dist
 
 

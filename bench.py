@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+XGMI_LINK_GBS = 153.0     # one xGMI link, MI355X_MICROARCH.md (7 links per GPU, point-to-point)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md "Chip-level parameters")
 METRIC = "rendered scene-seconds/sec @48kHz, 32-ch mic, 64 events, 2s RIR; 1/2/4/8 GPU"
 
@@ -451,21 +452,32 @@ def dropin_leg(scene, renderer, n: int):
         assert audio.shape == (scene.n_capsules, round(scene.duration * scene.sr)) and audio.dtype == np.float32
         return audio
 
+    world = ctx["world"] if ctx else 1
     try:
         for _ in range(2):
             one()
+        if ctx:
+            ctx["barrier"]()        # N > 1: every rank makes its calls at the same time (shared host DRAM / PCIe / NUMA)
         calls = []
         for _ in range(n):
             t0 = time.perf_counter()
             one()
             calls.append(time.perf_counter() - t0)
+        if ctx:
+            ctx["barrier"]()
         dt = float(np.median(calls))       # a synchronous host-side call sequence: the median call, the spread beside it
     finally:
         syn.set_renderer(None)
-    return {"value": scene.duration / dt, "unit": "scene-seconds/s", "ms_per_scene": dt * 1e3, "scenes": n,
-            "ms_per_scene_min_max": [round(min(calls) * 1e3, 2), round(max(calls) * 1e3, 2)],
-            "note": "Scene.generate() per scene, synchronous: host float32 clips + IR tensor in (H2D), render, mixdown, "
-                    "scene.audio out as a host ndarray (D2H); NOT the headline value"}
+    out = {"value": scene.duration / dt, "unit": "scene-seconds/s", "ms_per_scene": dt * 1e3, "scenes": n,
+           "ms_per_scene_min_max": [round(min(calls) * 1e3, 2), round(max(calls) * 1e3, 2)],
+           "note": "Scene.generate() per scene, synchronous: host float32 clips + IR tensor in (H2D), render, mixdown, "
+                   "scene.audio out as a host ndarray (D2H); NOT the headline value"}
+    if world > 1:
+        by_rank = ctx["all_ranks"](out["value"])
+        out.update(value=float(np.sum(by_rank)), value_by_rank=[round(v, 1) for v in by_rank], ranks_concurrent=world,
+                   ms_per_scene_this_rank=out["ms_per_scene"], ms_per_scene=scene.duration / float(np.sum(by_rank)) * 1e3,
+                   note=out["note"] + "; every rank calls at the same time: `value` = sum of the ranks' own rates")
+    return out
 
 
 def switches_in_effect() -> dict:
@@ -486,9 +498,23 @@ def source_hash() -> str:
     return h.hexdigest()[:16]
 
 
-def spawn_ranks(n: int) -> int:
+def dist_timeout():
+    """Timeout of every collective of a multi-rank run (both init_process_group calls; AL_DIST_TIMEOUT_S overrides): a rank that
+    dies leaves its siblings blocked for THIS long, not for the backend's default (RCCL: ten minutes)."""
+    from datetime import timedelta
+
+    return timedelta(seconds=float(os.environ.get("AL_DIST_TIMEOUT_S", "120")))
+
+
+def spawn_ranks(n: int, poll_s: float = 0.2, grace_s: float = 5.0) -> int:
     """`python bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) BEFORE this process
-    touches the GPU, with the same environment torch.distributed.run would give them; rank 0 prints the JSON line."""
+    touches the GPU, with the same environment torch.distributed.run would give them; rank 0 prints the JSON line.
+
+    The children are POLLED: the first one that exits non-zero (out of memory, a failed parity assert, a killed process) ends
+    the job -- the others are terminated (SIGTERM, SIGKILL after `grace_s`; they are children of a parent that never touched
+    the GPU, nothing is re-executed) and that exit code is returned, instead of waiting rank by rank for processes that sit in a
+    collective until the backend's watchdog fires."""
+    import signal
     import socket
     import subprocess
 
@@ -503,8 +529,32 @@ def spawn_ranks(n: int) -> int:
         # `hipIpcGetMemHandle: invalid argument`): kept for environments assembled by hand
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    codes = [p.wait() for p in procs]
-    return next((c for c in codes if c), 0)
+    failed = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            failed = next((c for c in codes if c not in (None, 0)), 0)
+            if failed or all(c is not None for c in codes):
+                break
+            time.sleep(poll_s)
+    except KeyboardInterrupt:
+        failed = 130
+    if failed:
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.send_signal(signal.SIGTERM)
+        deadline = time.monotonic() + grace_s
+        for p in alive:
+            try:
+                p.wait(timeout=max(deadline - time.monotonic(), 0.1))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        dead = [r for r, c in enumerate(codes) if c not in (None, 0)]
+        print(f"bench.py: rank {dead[0] if dead else '?'} exited with code {failed}; terminated {len(alive)} remaining rank(s)",
+              file=sys.stderr, flush=True)
+        return failed if failed > 0 else 128 - failed     # a signal's negative return code as the shell would report it
+    return 0
 
 
 def make_timers(emulate, torch):
@@ -620,11 +670,12 @@ def main():
                     help="events of every scene the all-cores leg renders (-1: a bounded sample, 6 for cfg2; 0: the whole scene, "
                          "which takes 128 busy cores about nine minutes at cfg2)")
     ap.add_argument("--end-to-end", type=int, default=None, metavar="N",
-                    help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; "
-                         "default 16 on one GPU, 0 otherwise)")
+                    help="also run N scenes through the pipelined batch driver from HOST buffers (PCIe-inclusive rate; with "
+                         "--gpus > 1 every rank runs it at the same time; default 16 per rank in the headline mode, 0 otherwise)")
     ap.add_argument("--dropin", type=int, default=None, metavar="N",
                     help="also time N calls of Scene.generate() (the drop-in API: host numpy clips + IRs in, scene.audio "
-                         "out, synchronous; default 8 on one GPU for static configs, 0 otherwise)")
+                         "out, synchronous; every rank at the same time with --gpus > 1; default 8 per rank for static configs in the "
+                         "headline mode, 0 otherwise)")
     ap.add_argument("--other-configs", type=int, default=1, metavar="0|1",
                     help="on the default single-GPU cfg2 run also time a few steps of cfg3, cfg4 and cfg5 (compact leg "
                          "`other_configs` of the JSON line; 0 = skip)")
@@ -651,11 +702,11 @@ def main():
     if args.cpu_events is None:
         args.cpu_events = {"cfg2": 64, "cfg3": 1, "cfg4": 32, "cfg5": 4}.get(args.config, 64)
     plain = args.total_scenes == 0 and args.shard == "scenes"
-    if args.end_to_end is None:
-        args.end_to_end = 16 if (world == 1 and plain) else 0
-    if args.dropin is None:
-        args.dropin = 8 if (world == 1 and plain) else 0
     emulate = os.environ.get("AL_BENCH_EMULATE") == "1"   # tests only: host-emulated kernels, numbers are NOT measurements
+    if args.end_to_end is None:     # N > 1: every rank runs the PCIe-inclusive legs at the same time (shared host)
+        args.end_to_end = 16 if (plain and not emulate) else 0    # (the batch driver needs page-locked memory and HIP streams)
+    if args.dropin is None:
+        args.dropin = 8 if plain else 0
 
     # SURVEY 8d (ii), the all-cores CPU figure: its worker processes are started HERE, before this process initialises the
     # GPU (a GPU-initialised process must not be the parent of an exec on this pool).  Under a profiler the preloaded tool
@@ -704,9 +755,9 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=dist_timeout())
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=dist_timeout())
     new_event, device_sync = make_timers(emulate, torch)
     coll_dev = "cuda" if (backend == "nccl" and not emulate) else "cpu"
     # N ranks on one node: each takes its share of the host (helper pools capped at usable CPUs / local ranks, the process pinned
@@ -870,13 +921,15 @@ def run_scene_per_rank_mode(ctx):
         out["other_configs"] = other_configs_leg(ctx, r)
         if any(not v.get("parity", {}).get("ok", True) for v in out["other_configs"].values()):
             out["_failed"] = True
+    multi = ctx if ctx["use_dist"] else None
     if args.end_to_end > 0:
-        out["end_to_end"] = end_to_end_leg(r, scene, args.end_to_end)
+        out["end_to_end"] = end_to_end_leg(r, scene, args.end_to_end, multi)
     if args.dropin > 0 and not emulate and not any(sp.is_moving for sp in scene.specs):
-        out["end_to_end_dropin"] = dropin_leg(scene, r, args.dropin)
+        out["end_to_end_dropin"] = dropin_leg(scene, r, args.dropin, multi)
     if (args.gather and world > 1) or (ctx["use_dist"] and world == 1):
         out["gather"], ok = gather_and_validate(ctx, r, scene_tensor(mix, scene, mix_plan, emulate, torch),
                                                 lambda peer: rerender(ctx, r, peer))
+        gather_vs_render(out["gather"], ms_per_step, 1, scene, world)
         out["_failed"] = not ok
     if rank == 0 and world == 1:
         ref_scene, ref_events = None, 0
@@ -1026,6 +1079,8 @@ def gather_and_validate(ctx, r, mine, rerender_fn, n_items=None, local=None):
         rec["bytes_over_links"] = moved
         rec["GBps_into_root"] = moved / (g_ms * 1e-3) / 1e9 if g_ms > 0 else None
         rec["GBps_per_peer_link"] = (moved / max(world - 1, 1)) / (g_ms * 1e-3) / 1e9 if (g_ms > 0 and world > 1) else None
+        rec["xgmi_link_peak_GBps"] = XGMI_LINK_GBS
+        rec["link_frac"] = rec["GBps_per_peer_link"] / XGMI_LINK_GBS if rec["GBps_per_peer_link"] else None
         checked = {}
         for item in sorted({i for i in (1, n_items - 1) if 0 < i < n_items and i % world != 0}):
             want = rerender_fn(item)
@@ -1037,9 +1092,29 @@ def gather_and_validate(ctx, r, mine, rerender_fn, n_items=None, local=None):
     return rec, ok
 
 
-def end_to_end_leg(r, scene, n):
+def gather_vs_render(rec, render_ms, scenes_per_rank, scene, world):
+    """The collection held against the rendering it follows: a peer renders `scenes_per_rank` scenes in `render_ms` and then sends them
+    over ITS OWN xGMI link.  render_ms_over_gather_ms < 1 means the links, not the kernels, set the pace of a job that collects
+    every scene on one rank (cfg2: 369 MB per 2.7 ms scene = 137 GB/s per peer link against ~153 GB/s)."""
+    if not rec.get("ms"):
+        return
+    scene_bytes = scene.n_capsules * round(scene.duration * scene.sr) * 4
+    rec["render_ms"] = render_ms
+    rec["render_ms_over_gather_ms"] = render_ms / rec["ms"]
+    rec["link_GBps_needed_to_keep_up"] = scenes_per_rank * scene_bytes / (render_ms * 1e-3) / 1e9 if world > 1 else None
+    rec["note"] += ("; link_GBps_needed_to_keep_up = one rank's rendered bytes / its render time: above xgmi_link_peak_GBps an overlapped "
+                    "gather is link-bound, not render-bound")
+
+
+def end_to_end_leg(r, scene, n, ctx=None):
+    """The pipelined batch driver from HOST buffers (PCIe-inclusive, never `value`).  With N > 1 EVERY rank runs it at the same
+    time -- each pass starts behind a barrier -- so the ranks contend for host DRAM, the PCIe root complexes and their NUMA nodes
+    as a multi-GPU dataset job would (core.py:1828-1847 of the reference: IRs from the host in, scene.audio out): the record then
+    carries per-rank rates, the aggregate over the slowest rank's wall time and the aggregate H2D + D2H rate."""
     from audiblelight_amd import batch as batch_mod
 
+    world = ctx["world"] if ctx else 1
+    barrier = ctx["barrier"] if ctx else (lambda: None)
     jobs = [batch_mod.SceneJob(specs=scene.specs, clips=scene.clips, irs=scene.irs, starts=scene.starts, ends=scene.ends,
                                duration=scene.duration, sample_rate=scene.sr, name=f"s{i}") for i in range(n)]
     per_scene_ambience = scene.ambience_beta is not None
@@ -1065,17 +1140,43 @@ def end_to_end_leg(r, scene, n):
     driver = batch_mod.BatchDriver(r)
     consume = lambda name, arr: None   # noqa: E731  (scene.audio delivered as a (C, T) float32 host array)
     driver.run((jobs * 2)[:6], on_scene=consume, copy_for_callback=False)   # warm-up: page-locks every staging slot once
-    reps = [driver.run(jobs, on_scene=consume, copy_for_callback=False) for _ in range(3)]
-    rep = max(reps, key=lambda r_: r_.scene_seconds_per_second)   # best of three passes (host-side noise is large)
-    return {"value": rep.scene_seconds_per_second, "unit": "scene-seconds/s", "scenes": rep.n_scenes,
-            "passes": [round(r_.scene_seconds_per_second, 1) for r_ in reps],
-            "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
-            "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
-            "ir_upload_bound": "one scene's IR tensor over PCIe at 56 GB/s = %.1f ms" % (scene.irs.nbytes / 56e9 * 1e3),
-            "ms_per_scene": 1e3 * rep.wall_s / max(rep.n_scenes, 1),
-            "ambience": "drawn per scene on the device (Philox), never on the host" if per_scene_ambience else None,
-            "note": "host float32 clips+IRs -> H2D -> render -> D2H of scene.audio into page-locked host memory, "
-                    "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+    reps, walls = [], []
+    for _ in range(3):
+        barrier()
+        rep = driver.run(jobs, on_scene=consume, copy_for_callback=False)
+        reps.append(rep)
+        walls.append(ctx["reduce_max"](rep.wall_s) if ctx else rep.wall_s)    # the slowest rank's wall time of THIS pass
+    barrier()
+    by_rank = [[v] for v in (r_.scene_seconds_per_second for r_ in reps)]
+    if ctx and world > 1:
+        by_rank = [ctx["all_ranks"](r_.scene_seconds_per_second) for r_ in reps]
+    return end_to_end_record(scene, reps, walls, by_rank, world, per_scene_ambience)
+
+
+def end_to_end_record(scene, reps, walls, by_rank, world, per_scene_ambience=False):
+    """The JSON record of the PCIe-inclusive leg from this rank's BatchReports (`reps`), the slowest rank's wall time of every pass
+    (`walls`) and every rank's own rate in every pass (`by_rank`): best pass by the slowest rank's wall time (host-side noise is
+    large); `value` = ALL ranks' scene-seconds over that wall time."""
+    best = min(range(len(reps)), key=lambda i: walls[i])
+    rep = reps[best]
+    out = {"value": world * rep.scene_seconds / walls[best], "unit": "scene-seconds/s", "scenes": world * rep.n_scenes,
+           "passes": [round(world * r_.scene_seconds / w, 1) for r_, w in zip(reps, walls)],
+           "h2d_bytes_per_scene": rep.h2d_bytes // max(rep.n_scenes, 1),
+           "d2h_bytes_per_scene": rep.d2h_bytes // max(rep.n_scenes, 1),
+           "ir_upload_bound": "one scene's IR tensor over PCIe at 56 GB/s = %.1f ms" % (scene.irs.nbytes / 56e9 * 1e3),
+           "ms_per_scene": 1e3 * walls[best] / max(world * rep.n_scenes, 1),
+           "ambience": "drawn per scene on the device (Philox), never on the host" if per_scene_ambience else None,
+           "note": "host float32 clips+IRs -> H2D -> render -> D2H of scene.audio into page-locked host memory, "
+                   "pipelined over scenes (audiblelight_amd/batch.py); PCIe-inclusive, NOT the headline value"}
+    if world > 1:
+        out.update(
+            value_by_rank=[round(v, 1) for v in by_rank[best]], value_per_rank_mean=float(np.mean(by_rank[best])),
+            ranks_concurrent=world,
+            host_GBps_aggregate={"h2d": world * rep.h2d_bytes / walls[best] / 1e9, "d2h": world * rep.d2h_bytes / walls[best] / 1e9,
+                                 "both": world * (rep.h2d_bytes + rep.d2h_bytes) / walls[best] / 1e9},
+            note=out["note"] + "; every rank runs this leg AT THE SAME TIME (passes start behind a barrier): `value` = all ranks' scene-"
+                               "seconds over the slowest rank's wall time of the best pass, value_by_rank = each rank's own rate in it")
+    return out
 
 
 def run_scene_batch_mode(ctx):
@@ -1132,6 +1233,7 @@ def run_scene_batch_mode(ctx):
             return scene_tensor(mix, sc, mix_plan, emulate, torch)
 
         out["gather"], ok = gather_and_validate(ctx, r, None, rerender_item, n_items=args.total_scenes, local=local)
+        gather_vs_render(out["gather"], float(np.median(rep_s)) / args.steps * 1e3, len(mine), scene0, world)
         # ... and the same collection OVERLAPPED with one more step of rendering: every scene is sent the moment it is
         # enqueued, rank 0 has its receives posted up front (distributed.render_and_gather_overlapped).  gather_overlap_ms is what
         # the collection costs a step once it hides behind the rendering (max over ranks), against `ms` above for doing it afterwards.

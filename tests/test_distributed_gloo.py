@@ -139,3 +139,103 @@ def test_two_rank_capsule_sharding(tmp_path):
     logs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), "\\n".join(logs)
     assert os.path.exists(out + "0") and os.path.exists(out + "1")
+
+
+def _bench_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AL_BENCH_EMULATE="1", AL_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    return env
+
+
+def _rank_children(launcher_pid, n, deadline_s=120.0):
+    """{rank: psutil.Process} of the launcher's children once all `n` of them carry RANK in their environment."""
+    import time
+
+    import psutil
+
+    t0 = time.monotonic()
+    while time.monotonic() - t0 < deadline_s:
+        found = {}
+        try:
+            for ch in psutil.Process(launcher_pid).children():
+                try:
+                    rk = ch.environ().get("RANK")
+                except (psutil.NoSuchProcess, psutil.AccessDenied):
+                    continue
+                if rk is not None:
+                    found[int(rk)] = ch
+        except psutil.NoSuchProcess:
+            return {}
+        if len(found) == n:
+            return found
+        time.sleep(0.1)
+    return {}
+
+
+def test_a_dead_rank_ends_the_job_in_seconds():
+    """`python bench.py --gpus 2` (gloo + host-emulated kernels here, RCCL on the GPU box) with rank 1 KILLED
+    mid-run.  The launcher polls its children: it must terminate rank 0 (which sits in a barrier / all-reduce waiting for the dead
+    peer) and exit non-zero within seconds -- not after the backend's watchdog (RCCL's default: ten minutes), and well inside the
+    150 s the review asks for."""
+    import signal
+    import time
+
+    from tests import hostemu
+
+    hostemu.build()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200000", "--warmup", "0", "--repeats", "1",
+           "--config", "cfg1", "--scale", "0.05", "--cpu-events", "0", "--end-to-end", "0", "--dropin", "0"]
+    t0 = time.monotonic()
+    launcher = subprocess.Popen(cmd, env=_bench_env(), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        ranks = _rank_children(launcher.pid, 2)
+        assert sorted(ranks) == [0, 1], "the launcher did not start two rank processes"
+        time.sleep(8.0)                                  # both ranks are past their imports and inside the timed steps
+        assert launcher.poll() is None and all(p.is_running() for p in ranks.values())
+        t_kill = time.monotonic()
+        ranks[1].send_signal(signal.SIGKILL)
+        _out, err = launcher.communicate(timeout=150)
+        took = time.monotonic() - t_kill
+    finally:
+        if launcher.poll() is None:
+            launcher.kill()
+    assert launcher.returncode not in (0, None), "a job that lost a rank must not report success"
+    assert took < 60, f"the launcher needed {took:.0f} s to give up after rank 1 died"
+    assert "terminated 1 remaining rank" in err and "rank 1 exited" in err
+    assert not ranks[0].is_running() or ranks[0].status() == "zombie", "rank 0 was left behind"
+    assert time.monotonic() - t0 < 150
+
+
+def test_a_rank_without_a_launcher_gives_up_on_a_dead_peer():
+    """The second net: ranks started by ANOTHER launcher (the driver uses torch.distributed.run) have no polling parent of ours.
+    Both init_process_group calls carry a timeout (AL_DIST_TIMEOUT_S, default 120 s): rank 0 must exit non-zero by itself soon after
+    rank 1 is killed instead of waiting in the collective for the backend's default."""
+    import signal
+    import time
+
+    from tests import hostemu
+
+    hostemu.build()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0", "--repeats", "10000000",
+           "--config", "cfg1", "--scale", "0.05", "--cpu-events", "0", "--end-to-end", "0", "--dropin", "0"]
+    procs = []
+    for rank in range(2):
+        env = dict(_bench_env(), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AL_DIST_TIMEOUT_S="20")
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    try:
+        time.sleep(12.0)
+        assert all(p.poll() is None for p in procs), [p.stderr.read()[-500:] for p in procs if p.poll() is not None]
+        t_kill = time.monotonic()
+        procs[1].send_signal(signal.SIGKILL)
+        procs[0].communicate(timeout=150)
+        took = time.monotonic() - t_kill
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    assert procs[0].returncode not in (0, None)
+    assert took < 120, f"rank 0 needed {took:.0f} s to give up on its dead peer"

@@ -171,6 +171,9 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     # the first multi-rank run validates itself: rank 0 renders rank 1's scene again and compares the gathered buffer bit for bit
     g = out["gather"]
     assert g["bytes_total"] > 0 and g["ranks_seen"] == [0, 1] and g["validated_against_local_rerender"] == {"1": True} and g["bit_exact"]
+    # the collection held against the rendering and against one xGMI link: the line says whether the links or the kernels set the pace
+    assert g["xgmi_link_peak_GBps"] == 153.0 and g["link_frac"] > 0 and g["render_ms_over_gather_ms"] > 0
+    assert g["link_GBps_needed_to_keep_up"] > 0 and g["render_ms"] == out["ms_per_step"]
     # BASELINE configs[3] as a mode: a batch of scenes split over the ranks, ALL of them gathered and two of them re-rendered
     out = run(["--total-scenes", "4", "--repeats", "1"])
     assert out["scaling"] == "strong" and out["config"]["total_scenes"] == 4 and out["config"]["scenes_this_rank"] == 2
@@ -658,3 +661,27 @@ print(int(pl.events["yspec_base"][1]), pl.xspec_blocks, int(mp.tile_ptr[-1]), pl
     assert res.stdout.split() == [str(int(full.events["yspec_base"][1])), str(full.xspec_blocks), str(int(mp.tile_ptr[-1])), "9",
                                   str(full.log2_block), str(full.batch_flags())]
     assert full.batch_flags() & _hip.FLAG_STATIC_MAC and not full.batch_flags() & _hip.FLAG_ONLY_STATIC
+
+
+def test_end_to_end_record_aggregates_over_concurrent_ranks():
+    """The PCIe-inclusive leg under N > 1 (every rank runs it at the same time): `value` is ALL ranks' scene-seconds over the SLOWEST
+    rank's wall time of the best pass, per-rank rates and the aggregate host traffic sit beside it; with one rank the record is the
+    single-GPU one."""
+    import types
+
+    import bench
+    from audiblelight_amd.batch import BatchReport
+
+    scene = types.SimpleNamespace(irs=np.zeros((2, 3, 1000), np.float32))
+    reps = [BatchReport(n_scenes=4, scene_seconds=240.0, wall_s=w, h2d_bytes=4 * 800, d2h_bytes=4 * 300) for w in (0.10, 0.08, 0.09)]
+    one = bench.end_to_end_record(scene, reps, [r.wall_s for r in reps], [[r.scene_seconds_per_second] for r in reps], 1)
+    assert one["value"] == 240.0 / 0.08 and one["scenes"] == 4 and "value_by_rank" not in one
+    assert one["h2d_bytes_per_scene"] == 800 and one["d2h_bytes_per_scene"] == 300
+    # four ranks; the slowest rank's wall time per pass is what the job waits for: the third pass is the best one
+    walls = [0.20, 0.16, 0.12]
+    by_rank = [[1200.0, 2400.0, 2000.0, 1500.0], [1500.0, 3000.0, 2500.0, 2000.0], [2000.0, 2666.7, 2400.0, 2200.0]]
+    four = bench.end_to_end_record(scene, reps, walls, by_rank, 4)
+    assert four["value"] == 4 * 240.0 / 0.12 and four["scenes"] == 16 and four["ranks_concurrent"] == 4
+    assert four["value_by_rank"] == [2000.0, 2666.7, 2400.0, 2200.0]
+    assert abs(four["host_GBps_aggregate"]["both"] - 4 * (3200 + 1200) / 0.12 / 1e9) < 1e-12
+    assert four["passes"] == [round(4 * 240.0 / w, 1) for w in walls] and "AT THE SAME TIME" in four["note"]

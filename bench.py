@@ -694,6 +694,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # AL_BENCH_DEVICE pins every rank to ONE device index (records of the N > 1 control flow with the real kernels on a box with
+    # fewer GPUs than ranks, profiles/tools/two_ranks_one_gpu_r06.sh; needs AL_DIST_BACKEND=gloo: RCCL refuses two ranks per device)
+    device_index = int(os.environ.get("AL_BENCH_DEVICE", local_rank))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch one rank per GPU "
                  f"(python bench.py --gpus N spawns them itself)")
@@ -745,7 +748,7 @@ def main():
     import torch
 
     if not emulate:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(device_index)
     backend = os.environ.get("AL_DIST_BACKEND", "nccl")   # "nccl" IS RCCL on ROCm; gloo only to exercise this path without N GPUs
     use_dist = world > 1 or os.environ.get("AL_BENCH_FORCE_DIST") == "1"   # the latter: exercise RCCL init with one rank
     dist = None
@@ -755,7 +758,7 @@ def main():
         if "MASTER_ADDR" not in os.environ:
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"), timeout=dist_timeout())
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{device_index}"), timeout=dist_timeout())
         else:
             dist.init_process_group(backend, timeout=dist_timeout())
     new_event, device_sync = make_timers(emulate, torch)
@@ -767,7 +770,7 @@ def main():
         from audiblelight_amd import distributed as _dist_mod, engine as _engine_mod
 
         local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        host_share = _dist_mod.host_share(local_rank, local_world, None if emulate else local_rank, pin=world > 1)
+        host_share = _dist_mod.host_share(local_rank, local_world, None if emulate else device_index, pin=world > 1)
         _engine_mod.set_thread_cap(host_share["threads"])
 
     def barrier():

@@ -181,13 +181,18 @@ class Augmentation:
             r.lib.call("al_wrap_copy", r.mem.ptr(clip.buf), clip.n, r.mem.ptr(dst), n_in, r.mem.stream())
             clip.swap(n_in)
 
+    def host_dtype(self, in_dtype: np.dtype) -> np.dtype:
+        """The dtype the reference's numpy code leaves a host array of ``in_dtype`` in (most FX keep it; Fade multiplies by a
+        float64 envelope, TimeWarpSilence splices float64 zeros in: augmentation.py:1554,1719)."""
+        return in_dtype
+
     def process(self, input_array: np.ndarray) -> np.ndarray:
         arr = np.asarray(input_array)
         if arr.ndim == 2:
             return np.stack([self.process(row) for row in arr])
         clip = DeviceClip(_renderer(), arr)
         self.process_device(clip)
-        return clip.host().astype(arr.dtype if np.issubdtype(arr.dtype, np.floating) else np.float32)
+        return clip.host().astype(self.host_dtype(arr.dtype if np.issubdtype(arr.dtype, np.floating) else np.dtype(np.float32)))
 
     def __call__(self, input_array: np.ndarray) -> np.ndarray:
         return self.process(input_array)
@@ -324,6 +329,9 @@ class Fade(EventAugmentation):
             raise ValueError(f"Expected `shape` to be one of {', '.join(self.FADE_SHAPES)} but got {given}")
         return given
 
+    def host_dtype(self, in_dtype):
+        return np.result_type(in_dtype, np.float64)
+
     def apply_device(self, clip):
         n_in = min(int(round(self.fade_in_len * self.sample_rate)), clip.n)
         n_out = min(int(round(self.fade_out_len * self.sample_rate)), clip.n)
@@ -367,9 +375,15 @@ class TimeWarp(EventAugmentation):
                     rows.append((r, 0))
             else:
                 rows.append((r, self.MODE if (hit and self.MODE) else 0))
+        self._spliced_zeros = self.MODE == 1 and any(mode == 1 for _, mode in rows)
         return (1 if fl > n else stride), row_len, rows
 
+    def host_dtype(self, in_dtype):
+        # TimeWarpSilence replaces a hit frame by np.zeros(len(frame)) -- float64 -- and np.concatenate widens the rest to it
+        return np.result_type(in_dtype, np.float64) if getattr(self, "_spliced_zeros", False) else in_dtype
+
     def apply_device(self, clip):
+        self._spliced_zeros = False
         if self.prob == 0:
             return
         stride, row_len, rows = self.row_plan(clip.n)

@@ -496,7 +496,7 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
     ``skip_existing``: a scene whose folder holds its metadata file (written last, from the writer path, as soon as the
     scene's last microphone is on disk) is left alone (benchmark.py:54-55); a folder an interrupted run left without it is
     rendered again.  ``metadata_dcase``: also
-    ``<metadata_fname>_<mic>.csv`` per microphone (``synthesize.generate_dcase2024_metadata``; the events need class indices
+    ``<metadata_fname>_<mic>.csv`` per microphone (``metadata.generate_dcase2024_metadata``; the events need class indices
     and emitter positions in their metadata).
 
     ``rank`` / ``world_size``: one process per GPU, every process handed the SAME scene stream; process ``rank`` renders
@@ -560,9 +560,9 @@ def render_dataset(scenes: Iterable, output_dir: str, skip_existing: bool = True
             per_mic = scene_jobs(scene, name, driver.r)
             frames = None
             if metadata_dcase:   # rows are tiny; computed while the scene object is still alive
-                from . import synthesize
+                from . import metadata
 
-                frames = synthesize.generate_dcase2024_metadata(scene)
+                frames = metadata.generate_dcase2024_metadata(scene)
             # only the (small) metadata dictionary outlives the scene: a dataset run must not keep every clip alive
             with meta_lock:
                 meta[name] = dict(dict=scene.to_dict() if hasattr(scene, "to_dict") else {}, left=len(per_mic), latency=0.0,

@@ -144,10 +144,19 @@ class Event:
         One upload, the chain on the device, one download (no intermediate copies between FX)."""
         if self.is_audio_loaded and not ignore_cache:
             return self.audio
-        out = self._chain(bool(ignore_cache)).host(normalize=bool(normalize))
+        out = self._chain(bool(ignore_cache)).host(normalize=bool(normalize)).astype(self.chain_dtype(), copy=False)
         valid_audio(out)
         self.audio = out
         return self.audio
+
+    def chain_dtype(self) -> np.dtype:
+        """The dtype the reference's FX chain leaves a float32 clip in (event.py:520-539 + the numpy FX of augmentation.py): float32
+        unless an FX widens it -- Fade's float64 envelope, a TimeWarpSilence that spliced float64 zeros in on its last run."""
+        dt = np.dtype(np.float32)
+        for a in self.augmentations:
+            if hasattr(a, "host_dtype"):
+                dt = np.dtype(a.host_dtype(dt))
+        return dt
 
     def clip_source(self, ignore_cache: Optional[bool] = False, chain_is_fresh: bool = False):
         """What the renderer needs of this event's clip WITHOUT bringing samples back to the host
@@ -375,7 +384,7 @@ class Scene:
         interleaved frames like ``soundfile.write(mic_audio.T, sr)`` (core.py:1840-1847) in soundfile's default WAV
         subtype ``PCM_16`` (``audio_subtype="FLOAT"`` keeps float32); frames are encoded on the device.
         ``metadata_json``: write ``<metadata_fname>.json`` (``to_dict``) when ``output_dir`` is given.
-        ``metadata_dcase``: write ``<metadata_fname>_<mic>.csv`` (``synthesize.generate_dcase2024_metadata``, host
+        ``metadata_dcase``: write ``<metadata_fname>_<mic>.csv`` (``metadata.generate_dcase2024_metadata``, host
         bookkeeping; on by default like the reference, core.py:1794; it needs class indices and emitter positions in the
         events' metadata and raises the reference's error without them: pass ``metadata_dcase=False`` for events built from
         bare arrays).  ``video`` belongs to a host-side subsystem that is out of scope: asking for it raises
@@ -403,9 +412,9 @@ class Scene:
         if metadata_json and output_dir is not None:
             self.to_json(os.path.join(output_dir, os.path.splitext(str(metadata_fname))[0] + ".json"))
         if metadata_dcase and output_dir is not None:       # one CSV per microphone, no header (core.py:1864-1874)
-            from . import synthesize
+            from . import metadata
 
             stem = os.path.splitext(str(metadata_fname))[0]
-            for mic, df in synthesize.generate_dcase2024_metadata(self).items():
+            for mic, df in metadata.generate_dcase2024_metadata(self).items():
                 df.to_csv(os.path.join(output_dir, f"{stem}_{mic}.csv"), sep=",", encoding="utf-8", header=None)
         return self.audio

@@ -319,13 +319,14 @@ class RenderResult:
             self.lib.call("al_scale_rows_f64", self.memory.ptr(tmp), n, p, self.memory.stream())
         return tmp
 
-    def spatial_audio(self, i: int) -> np.ndarray:
+    def spatial_audio(self, i: int, dtype=np.float64) -> np.ndarray:
         """event.spatial_audio[mic]: the scaled (C, La) render (synthesize.py:599,606), scaled by event_scale[i] on the device
-        and widened to float64 (the reference's dtype) after the copy."""
+        and widened to ``dtype`` after the copy (the reference's: float64, except float32 for a float32 clip tiled over the capsules
+        or convolved with float32 IRs -- synthesize._reference_dtype)."""
         ev = self.plan.events[i]
         n = self.plan.n_capsules * int(ev["len"])
         dev = self.scaled_copy(int(ev["out_off"]), n, [self.memory.ptr(self.event_scale) + 4 * i])
-        return self.memory.download(dev)[:n].reshape(self.plan.n_capsules, int(ev["len"])).astype(np.float64)
+        return self.memory.download(dev)[:n].reshape(self.plan.n_capsules, int(ev["len"])).astype(dtype)
 
 
 class Renderer:

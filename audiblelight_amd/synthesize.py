@@ -278,11 +278,19 @@ def _clip_of(event, ignore_cache: bool, chain_is_fresh: bool = False):
     """The event's clip for the renderer: ``engine.ClipSource`` from events that can hand it over without a host
     round trip (core.Event.clip_source: device FX chain, folded Gain/Invert + peak normalisation), else the array
     ``event.load_audio()`` returns (reference Events: event.py:496-539)."""
+    return _clip_and_dtype(event, ignore_cache, chain_is_fresh)[0]
+
+
+def _clip_and_dtype(event, ignore_cache: bool, chain_is_fresh: bool = False):
+    """(``_clip_of``'s clip, the dtype ``event.load_audio()`` hands the reference's arithmetic: float32 for this package's Events
+    and for the reference's, librosa.load's dtype; whatever a duck-typed event returns otherwise)."""
     if hasattr(event, "clip_source"):
-        return event.clip_source(ignore_cache=ignore_cache, chain_is_fresh=chain_is_fresh)
+        src = event.clip_source(ignore_cache=ignore_cache, chain_is_fresh=chain_is_fresh)
+        loaded = getattr(event, "is_audio_loaded", False) and not ignore_cache and isinstance(getattr(event, "audio", None), np.ndarray)
+        return src, (event.audio.dtype if loaded else event.chain_dtype() if hasattr(event, "chain_dtype") else np.dtype(np.float32))
     audio = event.load_audio(ignore_cache=ignore_cache, normalize=True)
     valid_audio(audio)
-    return np.ascontiguousarray(audio, dtype=np.float32)
+    return np.ascontiguousarray(audio, dtype=np.float32), audio.dtype
 
 
 def _spec_of(event, clip: np.ndarray, n_emitters: int, emitter0: int, ref_db: float) -> planning.EventSpec:
@@ -298,14 +306,32 @@ def _spec_of(event, clip: np.ndarray, n_emitters: int, emitter0: int, ref_db: fl
                               ref_db=float(ref_db))
 
 
-def _publish(event, mic_alias: str, res: engine.RenderResult, index: int) -> None:
-    """event.spatial_audio[mic] = scaled (C, La) render, kept in HBM until read (synthesize.py:606)."""
+def _reference_dtype(a_dt, n_emitters: int, irs) -> np.dtype:
+    """The dtype the reference's arithmetic leaves ``event.spatial_audio[mic]`` (and the dry render) in (synthesize.py:560-599 under
+    NumPy 2's weak Python scalars): a clip tiled over the capsules keeps the CLIP's dtype (float32 from Event.load_audio), a static
+    event has fftconvolve's result type of clip and IRs (float32 only if both are), a moving event passes through complex128 STFTs and
+    is float64 whatever went in."""
+    a_dt = np.dtype(a_dt)
+    if n_emitters == 0:
+        return a_dt
+    if n_emitters > 1:
+        return np.dtype(np.float64)
+    i_dt = getattr(irs, "dtype", np.float64)
+    try:
+        i_dt = np.dtype(i_dt)
+    except TypeError:                                   # a device tensor's dtype ("torch.float32"): by name, nothing is copied
+        i_dt = np.dtype(str(i_dt).rpartition(".")[2])
+    return np.result_type(a_dt, i_dt if np.issubdtype(i_dt, np.floating) else np.float64)
+
+
+def _publish(event, mic_alias: str, res: engine.RenderResult, index: int, dtype=np.float64) -> None:
+    """event.spatial_audio[mic] = scaled (C, La) render, kept in HBM until read (synthesize.py:606), handed back in ``dtype``."""
     event.spatial_audio = as_lazy(getattr(event, "spatial_audio", None))
     n_ch, n_samp = res.plan.n_capsules, int(res.plan.events["len"][index])
 
     def fetch():
         res.check_finite()      # librosa.util.valid_audio of synthesize.py:603: raised when the render first meets the host
-        out = res.spatial_audio(index)
+        out = res.spatial_audio(index, dtype)
         validate_shape(out.shape, (n_ch, n_samp))
         return out
 
@@ -375,27 +401,28 @@ def _dry_batch(r: engine.Renderer, items, mic_alias: str, res: engine.RenderResu
             ir[peak + hi:] = 0
         if peak - lo > 0:
             ir[: peak - lo] = 0
-        clip = np.asarray(event.load_audio(ignore_cache=False), dtype=np.float32)
-        todo.append((event, ir, clip, index, em0))
+        audio = event.load_audio(ignore_cache=False)
+        clip = np.asarray(audio, dtype=np.float32)
+        todo.append((event, ir, clip, index, em0, _reference_dtype(np.asarray(audio).dtype, 1, irs)))
     if not todo:
         return
     n_ir = todo[0][1].shape[0]
     specs = [planning.EventSpec(n_samples=len(clip) + n_ir - 1, n_emitters=1, snr=1.0, emitter0=j)
-             for j, (_, _, clip, _, _) in enumerate(todo)]
-    clips = [np.concatenate([clip, np.zeros(n_ir - 1, np.float32)]) for _, _, clip, _, _ in todo]
+             for j, (_, _, clip, _, _, _) in enumerate(todo)]
+    clips = [np.concatenate([clip, np.zeros(n_ir - 1, np.float32)]) for _, _, clip, _, _, _ in todo]
     pl = planning.plan_batch(specs, 1, n_ir, todo[0][0].sample_rate, lib=r.lib)
-    dry = r.prepare(pl, clips, np.stack([ir for _, ir, _, _, _ in todo])[None, :, :], normalize_irs=False)
+    dry = r.prepare(pl, clips, np.stack([ir for _, ir, _, _, _, _ in todo])[None, :, :], normalize_irs=False)
     dry_res = dry.run(("al_forward_spectra", "al_emitter_gains", "al_spectral_mac", "al_block_synthesis"))
-    for j, (event, _, _, index, em0) in enumerate(todo):
-        def fetch(j=j, index=index, em0=em0):
+    for j, (event, _, _, index, em0, dtype) in enumerate(todo):
+        def fetch(j=j, index=index, em0=em0, dtype=dtype):
             # scaled on the device by the two results of the MAIN render it depends on -- emitter_gain[em0] (normalize_irs) and
             # event_stats[index][3], the noise-floor multiplier the reference calls event_scale (synthesize.py:598,608) --
-            # and widened to float64 after the copy
+            # and widened to the reference's dtype (float64 unless clip AND IRs are float32) after the copy
             ev = dry_res.plan.events[j]
             mem = res.memory
             dev = dry_res.scaled_copy(int(ev["out_off"]), int(ev["len"]), [mem.ptr(res.emitter_gain) + 4 * em0],
                                       [mem.ptr(res.event_stats) + 8 * (4 * index + 3)])
-            return mem.download(dev)[: int(ev["len"])].astype(np.float64)
+            return mem.download(dev)[: int(ev["len"])].astype(dtype)
 
         event._spatial_audio_dry = as_lazy(getattr(event, "_spatial_audio_dry", None))
         LazyAudioDict.__setitem__(event._spatial_audio_dry, mic_alias, fetch)
@@ -460,7 +487,7 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
         return
     n_ch, n_emitters, n_ir = irs.shape
     fft_size, win_size, hop_size = int(fft_size), int(win_size), int(hop_size)
-    clip = _clip_of(event, bool(ignore_cache))
+    clip, clip_dtype = _clip_and_dtype(event, bool(ignore_cache))
     spec = _spec_of(event, clip, n_emitters, 0, ref_db)
     r = get_renderer()
     if n_emitters > 1:
@@ -472,7 +499,7 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
         pl = planning.plan_batch([spec], n_ch, max(n_ir, 1), event.sample_rate, lib=r.lib, **geometry)
         res = r.render(pl, [clip], irs)
     res.check_finite()
-    _publish(event, mic_alias, res, 0)
+    _publish(event, mic_alias, res, 0, _reference_dtype(clip_dtype, n_emitters, irs))
     _dry_batch(r, [(event, irs, 0, 0)], mic_alias, res)
 
 
@@ -518,10 +545,10 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
             n_emit = len(event)
             cached = mic_alias in getattr(event, "spatial_audio", {}).keys() and not ignore_cache
             if not cached:
-                clip = _clip_of(event, bool(ignore_cache), any(event is f for f in fresh))
+                clip, clip_dtype = _clip_and_dtype(event, bool(ignore_cache), any(event is f for f in fresh))
                 specs.append(_spec_of(event, clip, n_emit, counter, scene.ref_db))
                 clips.append(clip)
-                todo.append((event, counter))
+                todo.append((event, counter, clip_dtype))
             counter += n_emit
         if not specs:
             continue
@@ -530,9 +557,9 @@ def render_audio_for_all_scene_events(scene, ignore_cache: Optional[bool] = Fals
         # synthesize.py:603) is made where the results first meet the host: in generate_scene_audio_from_events (one combined
         # download of every statistic of the scene) or on the first read of event.spatial_audio[mic].
         res = r.render(pl, clips, ir_on_device.pop(mic_alias, mic_ir))
-        for i, (event, em0) in enumerate(todo):
-            _publish(event, mic_alias, res, i)
-        _dry_batch(r, [(event, mic_ir[:, em0: em0 + len(event), :], i, em0) for i, (event, em0) in enumerate(todo)],
+        for i, (event, em0, clip_dtype) in enumerate(todo):
+            _publish(event, mic_alias, res, i, _reference_dtype(clip_dtype, len(event), mic_ir))
+        _dry_batch(r, [(event, mic_ir[:, em0: em0 + len(event), :], i, em0) for i, (event, em0, _) in enumerate(todo)],
                    mic_alias, res)
     logger.info(f"Rendered scene audio in {(time() - start):.2f} seconds!")
 
@@ -767,59 +794,11 @@ def validate_scene(scene) -> None:
                          f"{ctx.get_listener_count()} listeners. Have any been orphaned?")
 
 
-# ----------------------------------------------------------------------------- DCASE-2024 metadata (host, no samples involved)
-DCASE_2024_COLUMNS = ["frame_number", "active_class_index", "source_number_index", "azimuth", "elevation", "distance"]
+def __getattr__(name):
+    # the reference keeps generate_dcase2024_metadata in synthesize.py (:742-878); here it is host bookkeeping outside the hot path
+    # (audiblelight_amd/metadata.py), reachable under the reference's name without this module importing it
+    if name in ("generate_dcase2024_metadata", "DCASE_2024_COLUMNS"):
+        from . import metadata
 
-
-def _polar_of(event, mic: str) -> np.ndarray:
-    """(n_emitters, 3) azimuth / elevation (degrees) and distance (metres) of an event's emitters relative to ``mic``: the
-    reference's ``Emitter.coordinates_relative_polar[mic]`` objects, or the ``emitters_relative`` block of its metadata."""
-    emitters = getattr(event, "emitters", None)
-    if emitters and hasattr(emitters[0], "coordinates_relative_polar"):
-        return np.vstack([np.asarray(e.coordinates_relative_polar[mic], dtype=float).reshape(-1, 3) for e in emitters])
-    rel = getattr(event, "emitters_relative", None) or getattr(event, "metadata", {}).get("emitters_relative")
-    if not rel or mic not in rel:
-        raise ValueError(f"Event {getattr(event, 'alias', '?')} carries no emitter positions relative to {mic}: "
-                         "DCASE metadata needs them (Event.metadata['emitters_relative'])")
-    return np.asarray(rel[mic], dtype=float).reshape(-1, 3)
-
-
-def generate_dcase2024_metadata(scene, temporal_resolution=0.1):
-    """DCASE-2024 rows per microphone (reference synthesize.py:742-878): one row per active 100 ms frame and event --
-    frame, class index, source index (counted per class in order of appearance; events sharing an audio file share it),
-    rounded azimuth / elevation in degrees and distance in centimetres, linearly interpolated over the emitters of a moving
-    event; sorted by (frame, class, source), indexed by frame.  Pure host bookkeeping (pandas), no samples involved."""
-    import pandas as pd
-
-    frames = np.round(np.arange(0, scene.duration + temporal_resolution, temporal_resolution), 1)
-    microphones = list(scene.state.microphones.keys())
-    rows = {mic: [] for mic in microphones}
-    events = scene.get_events() if hasattr(scene, "get_events") else list(scene.events.values())
-    next_source: Dict[int, int] = {}
-    source_of_file: Dict[str, int] = {}
-
-    def frame_of(t: float) -> int:
-        return int(np.where(frames == round(t, 1))[0][0])
-
-    for event in sorted(events, key=lambda e: e.scene_start):
-        span = np.arange(frame_of(max(event.scene_start, 0.0)), frame_of(min(event.scene_end, scene.duration)) + 1)
-        if not isinstance(event.class_id, int):
-            raise ValueError("Can't convert Event to DCASE format without valid DCASE class indices")
-        fname = getattr(event, "filename", None)
-        if fname not in source_of_file:
-            source_of_file[fname] = next_source.get(event.class_id, 0)
-            next_source[event.class_id] = next_source.get(event.class_id, 0) + 1
-        source = source_of_file[fname]
-        for mic in microphones:
-            polar = _polar_of(event, mic)
-            if not event.is_moving:
-                track = np.repeat(polar[:1], len(span), axis=0)
-            else:
-                times = frames[span]
-                knots = np.linspace(times.min(), times.max(), num=len(polar))
-                track = np.stack([np.interp(times, knots, polar[:, d]) for d in range(3)], axis=1)
-            for idx, (az, el, dist) in zip(span, track):
-                rows[mic].append([int(idx), event.class_id, source, round(az), round(el), round(dist * 100)])
-    return {mic: pd.DataFrame(data, columns=DCASE_2024_COLUMNS)
-            .sort_values(["frame_number", "active_class_index", "source_number_index"]).set_index("frame_number")
-            for mic, data in rows.items()}
+        return getattr(metadata, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

@@ -435,7 +435,7 @@ def load_pmc_valu(config: str, log2_block: int):
     return table.get(f"{config}/log2_block={log2_block}/valu_insts")
 
 
-def dropin_leg(scene, renderer, n: int):
+def dropin_leg(scene, renderer, n: int, ctx=None):
     """The reference's own call sequence on this package's objects: a Scene built from host numpy clips + IRs,
     ``Scene.generate()`` = render_audio_for_all_scene_events + generate_scene_audio_from_events (core.py:1828-1847),
     ``scene.audio[mic]`` back as a host ndarray.  Synchronous, one scene at a time, PCIe both ways inside the timing."""
@@ -486,15 +486,43 @@ def switches_in_effect() -> dict:
     return switches.current().non_default()
 
 
+def strip_c_comments(text: str) -> str:
+    """C / C++ source without its comments and with every run of white space collapsed to one blank (string and character
+    literals are kept as they are): two sources with the same result compile to the same code object."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        ch = text[i]
+        if ch in "\"'":                                     # literal: copy up to the matching quote, escapes included
+            j = i + 1
+            while j < n and text[j] != ch:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i: j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            while j > 0 and text[j - 1] == "\\":            # a line comment continued by a backslash
+                j = text.find("\n", j + 1)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append(" ")
+            i = n if j < 0 else j + 2
+        else:
+            out.append(ch)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def source_hash() -> str:
-    """Hash of the kernel sources: ties profiles/pmc_traffic.json to the build it was measured on."""
+    """Hash of the kernel sources AS THE COMPILER SEES THEM (comments and white space stripped): ties profiles/pmc_traffic.json to the
+    build it was measured on without a comment edit invalidating four configs x three PMC passes of GPU time."""
     import hashlib
 
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "audiblelight_amd", "csrc")
     for name in sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))):
         h.update(name.encode())
-        h.update(open(os.path.join(csrc, name), "rb").read())
+        h.update(strip_c_comments(open(os.path.join(csrc, name), encoding="utf-8").read()).encode())
     return h.hexdigest()[:16]
 
 

@@ -23,7 +23,7 @@ for l in open("gpurun_out/two_r06_line.txt"):
 PY
 tail -3 gpurun_out/two_r06_err.txt
 echo "---- a rank killed mid-run"
-T0=$(date +%s.%N)
+T0=$(date +%s)
 python bench.py --gpus 2 --config cfg2 --steps 2000000 --warmup 2 --repeats 1 --cpu-events 0 --end-to-end 0 --dropin 0 > gpurun_out/two_r06_dead.txt 2>&1 &
 LAUNCHER=$!
 sleep 45
@@ -31,10 +31,10 @@ VICTIM=""
 for p in $(pgrep -P $LAUNCHER); do
   if tr '\0' '\n' < /proc/$p/environ | grep -qx "RANK=1"; then VICTIM=$p; fi
 done
-echo "launcher $LAUNCHER, rank 1 is pid $VICTIM, killing it $(echo "$(date +%s.%N) - $T0" | bc) s after the start"
-TK=$(date +%s.%N)
+echo "launcher $LAUNCHER, rank 1 is pid $VICTIM, killing it $(( $(date +%s) - T0 )) s after the start"
+TK=$(date +%s)
 kill -9 $VICTIM
 wait $LAUNCHER
 CODE=$?
-echo "launcher exit code $CODE, $(echo "$(date +%s.%N) - $TK" | bc) s after the kill"
+echo "launcher exit code $CODE, $(( $(date +%s) - TK )) s after the kill"
 tail -2 gpurun_out/two_r06_dead.txt

@@ -7,7 +7,8 @@ same duck-typed objects: by the reference's own ``render_audio_for_all_scene_eve
 (numpy / scipy, imported from /root/reference exactly as tests/golden/make_golden.py does) and by this package's functions of
 the same names over the host-emulated kernels (the unmodified kernel sources compiled for the CPU; the gfx950 build runs the
 same scenes in the GPU suite through the oracle).  Every event's ``spatial_audio`` and every ``scene.audio`` must agree within
-the contract's bound (1e-4 relative RMS and max-abs / max|ref|); silent results must be silent on both sides.
+the contract's bound (1e-4 relative RMS and max-abs / max|ref|) AND carry the reference's dtype (a float32 clip tiled over the
+capsules stays float32, synthesize.py:572-599); silent results must be silent on both sides.
 
     python tests/golden/differential_fuzz.py [FIRST LAST]        (default 0 200; prints the worst case, exit code 1 on a failure)
 """
@@ -60,6 +61,14 @@ def random_scene(seed, amb_mod):
     mic_ir = np.concatenate(irs, axis=1)
     if mic_ir.shape[1] == 0:                                        # the reference refuses a WorldState without emitters
         return None
+    # dtypes the reference's arithmetic keeps or widens (a generator of its own: the scenes of earlier records stay the same):
+    # float32 IRs (static renders and dry renders stay float32), the odd float64 clip (a tiled clip stays float64)
+    drng = np.random.default_rng(90_000 + seed)
+    if drng.random() < 0.3:
+        mic_ir = mic_ir.astype(np.float32)
+    for ev in events.values():
+        if drng.random() < 0.15:
+            ev._audio = ev._audio.astype(np.float64)
     noise = rng.choice([None, None, "white", "pink", 1.5])
     ambience = {}
     if noise is not None:
@@ -128,6 +137,8 @@ def geometry_case(seed, ref_syn, ours):
 
 
 def errors(got, ref):
+    if np.asarray(got).dtype != np.asarray(ref).dtype:      # a drop-in hands back the reference's dtype, not only its values
+        return float("inf"), float("inf")
     got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
     if got.shape != ref.shape:
         return float("inf"), float("inf")
@@ -174,7 +185,7 @@ def main():
             if max(rms, mx) > worst[0]:
                 worst = (max(rms, mx), (seed, what))
             if rms > 1e-4 or mx > 1e-4:
-                bad.append((seed, what, rms, mx))
+                bad.append((seed, what, rms, mx, str(np.asarray(got).dtype), str(np.asarray(ref).dtype)))
     # the FX the reference implements in numpy and its coloured-noise generator, same seeds on both sides
     import audiblelight.augmentation as ref_aug
     from audiblelight_amd import ambience as our_amb, augmentation as our_aug
@@ -191,7 +202,7 @@ def main():
             if max(rms, mx) > worst[0]:
                 worst = (max(rms, mx), (seed, what))
             if rms > 1e-4 or mx > 1e-4:
-                bad.append((seed, what, rms, mx))
+                bad.append((seed, what, rms, mx, str(np.asarray(got).dtype), str(np.asarray(ref).dtype)))
     ours.set_renderer(None)
     print(f"{n_fx} of the arrays are FX / coloured-noise outputs (Fade, Invert, Reverse, TimeWarp*, powerlaw_psd_gaussian) and moving events "
           f"under random STFT geometries")

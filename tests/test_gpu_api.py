@@ -24,6 +24,7 @@ test_scene_generate_matches_reference = scenarios.test_scene_generate_matches_re
 test_render_cache_and_host_arrays = scenarios.test_render_cache_and_host_arrays
 test_render_event_audio_and_errors = scenarios.test_render_event_audio_and_errors
 test_validate_scene_messages = scenarios.test_validate_scene_messages
+test_outputs_carry_the_reference_dtype = scenarios.test_outputs_carry_the_reference_dtype
 test_standalone_convolutions = scenarios.test_standalone_convolutions
 test_pointwise_fx_match_definitions = scenarios.test_pointwise_fx_match_definitions
 test_timewarp_matches_reference_semantics = scenarios.test_timewarp_matches_reference_semantics

@@ -685,3 +685,30 @@ def test_end_to_end_record_aggregates_over_concurrent_ranks():
     assert four["value_by_rank"] == [2000.0, 2666.7, 2400.0, 2200.0]
     assert abs(four["host_GBps_aggregate"]["both"] - 4 * (3200 + 1200) / 0.12 / 1e9) < 1e-12
     assert four["passes"] == [round(4 * 240.0 / w, 1) for w in walls] and "AT THE SAME TIME" in four["note"]
+
+
+def test_source_hash_ignores_comments_but_not_code(tmp_path, monkeypatch):
+    """profiles/pmc_traffic.json is tied to the kernel sources by bench.source_hash(): a comment or white-space edit must leave the
+    committed table valid (round 5 re-collected four configs x three PMC passes seven times for such edits), any change of a token
+    must not; and the committed table matches the sources of this tree."""
+    import json
+    import shutil
+
+    import bench
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    table = json.load(open(os.path.join(root, "profiles", "pmc_traffic.json")))
+    assert table["source_hash"] == bench.source_hash(), "pmc_traffic.json was measured on other kernel sources: re-collect (profiles/tools/collect_profiles.sh)"
+    copy = tmp_path / "audiblelight_amd" / "csrc"
+    shutil.copytree(os.path.join(root, "audiblelight_amd", "csrc"), copy, ignore=shutil.ignore_patterns("*.o", "*.so"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.source_hash() == table["source_hash"]
+    src = copy / "al_kernels.hip"
+    text = src.read_text()
+    src.write_text("// a new first line\n" + text.replace("\n", "   \n", 40).replace("{\n", "{  /* why */\n", 5))
+    assert bench.source_hash() == table["source_hash"], "a comment / white-space edit changed the hash"
+    src.write_text(text.replace("__launch_bounds__(64)", "__launch_bounds__(128)", 1))
+    assert bench.source_hash() != table["source_hash"], "a code edit did not change the hash"
+    # literals are code: "//" inside a string is not a comment
+    assert bench.strip_c_comments('a = "x // y"; // z') == 'a = "x // y";'
+    assert bench.strip_c_comments("f(/* in */ 1,\n  2)  // tail") == "f( 1, 2)"

@@ -112,6 +112,41 @@ def test_render_event_audio_and_errors(golden):
         syn.render_event_audio(bad, h, "mic000")
 
 
+def test_outputs_carry_the_reference_dtype(golden):
+    """A drop-in hands back the reference's dtypes, not only its values (synthesize.py:560-599 under NumPy 2's weak scalars, measured on
+    the reference itself: tests/golden/differential_fuzz.py compares dtypes on every array): a clip tiled over the capsules keeps the
+    clip's dtype -- float32 from Event.load_audio, the golden G2 is float32 --, a static render and its dry render have fftconvolve's
+    result type of clip and IRs, a moving render is float64 whatever went in; Fade and a TimeWarpSilence that silenced a frame
+    widen a float32 clip to float64, the other numpy FX keep it."""
+    import types
+
+    def duck(audio, n_emitters, **kw):
+        return types.SimpleNamespace(alias="d", snr=7.0, sample_rate=8000, is_moving=n_emitters > 1, spatial_audio={}, _spatial_audio_dry={},
+                                     duration=len(audio) / 8000,
+                                     load_audio=lambda ignore_cache=False, normalize=True: audio, __len__=lambda: n_emitters,
+                                     ref_ir_channel=kw.get("ref"), direct_path_time_ms=kw.get("win"))
+
+    a32, h64 = golden["g2_audio"], golden["g1_irs"].astype(np.float64)[:, :, :400]
+    assert a32.dtype == np.float32 and golden["g2_spatial"].dtype == np.float32
+    cases = [(a32, np.zeros((4, 0, 100)), np.float32), (a32.astype(np.float64), np.zeros((4, 0, 100)), np.float64),
+             (a32, h64, np.float64), (a32, h64.astype(np.float32), np.float32), (a32.astype(np.float64), h64.astype(np.float32), np.float64),
+             (a32, np.repeat(h64.astype(np.float32), 3, 1), np.float64)]
+    for audio, irs, want in cases:
+        ev = duck(audio, irs.shape[1], ref=1 if irs.shape[1] == 1 else None, win=[2, 20] if irs.shape[1] == 1 else None)
+        syn.render_event_audio(ev, irs, "m", ref_db=-65)
+        assert ev.spatial_audio["m"].dtype == want, (audio.dtype, irs.dtype, irs.shape[1])
+        if irs.shape[1] == 1:
+            assert ev._spatial_audio_dry["m"].dtype == want
+    ev = duck(a32, 0)
+    syn.render_event_audio(ev, np.zeros((4, 0, 100)), "m", ref_db=-65)
+    assert_parity(ev.spatial_audio["m"], golden["g2_spatial"], 1e-6)
+    assert aug.Fade(8000, fade_in_len=0.1, fade_out_len=0.1, fade_in_shape="linear", fade_out_shape="linear")(a32).dtype == np.float64
+    assert aug.Invert(8000)(a32).dtype == np.float32 and aug.Reverse(8000)(a32).dtype == np.float32
+    assert aug.TimeWarpSilence(8000, fps=8.0, prob=1.0)(a32).dtype == np.float64
+    assert aug.TimeWarpSilence(8000, fps=8.0, prob=0.0)(a32).dtype == np.float32
+    assert aug.TimeWarpReverse(8000, fps=8.0, prob=1.0)(a32).dtype == np.float32
+
+
 def test_validate_scene_messages(golden):
     scene = build_g8_scene(golden, with_ambience=False)
     syn.validate_scene(scene)
@@ -656,7 +691,7 @@ def test_fx_match_the_reference_classes_outputs():
         a, b, la, lb, src = str(case).split(",")
         x = z["x_short" if src == "short" else "x"]
         got = aug.Fade(sample_rate=sr, fade_in_len=float(la), fade_out_len=float(lb), fade_in_shape=a, fade_out_shape=b)(x)
-        assert got.shape == x.shape and got.dtype == np.float32
+        assert got.shape == x.shape and got.dtype == z[f"fade_{i}"].dtype == np.float64    # float32 clip x float64 envelope
         np.testing.assert_allclose(got, z[f"fade_{i}"], rtol=0, atol=3e-7, err_msg=str(case))
     np.testing.assert_array_equal(aug.Invert(sample_rate=sr)(z["x"]), z["invert"])
     np.testing.assert_array_equal(aug.Reverse(sample_rate=sr)(z["x"]), z["reverse"])
@@ -664,7 +699,9 @@ def test_fx_match_the_reference_classes_outputs():
         name, fps, prob, src, seed = str(case).split(",")
         fx = getattr(aug, name)(sample_rate=sr, fps=float(fps), prob=float(prob))
         random.seed(int(seed))
-        np.testing.assert_array_equal(fx(z[src]), z[f"tw_{i}"].astype(np.float32), err_msg=str(case))
+        got = fx(z[src])
+        assert got.dtype == z[f"tw_{i}"].dtype, str(case)     # float64 where the reference spliced np.zeros(len(frame)) in
+        np.testing.assert_array_equal(got, z[f"tw_{i}"], err_msg=str(case))
 
 
 def test_ambience_file_mode_matches_the_reference(tmp_path):

@@ -264,8 +264,14 @@ class PlannerLibrary:
 _planner: Optional[PlannerLibrary] = None
 
 
-def get_planner() -> PlannerLibrary:
+def get_planner():
+    """The planner-only library; where it is absent (a tree built before it existed, or only AUDIBLELIGHT_HIP_LIB pointing at a
+    custom / sanitizer build) the FULL library, which exports the same al_plan_* symbols.  Raises only if neither exists."""
     global _planner
     if _planner is None:
-        _planner = PlannerLibrary()
+        path = os.environ.get("AUDIBLELIGHT_PLAN_LIB") or DEFAULT_PLANNER
+        if os.path.exists(path) or not os.path.exists(os.environ.get("AUDIBLELIGHT_HIP_LIB") or DEFAULT_LIB):
+            _planner = PlannerLibrary(path)      # (raises with the build hint when neither library is there)
+        else:
+            _planner = get_library()
     return _planner

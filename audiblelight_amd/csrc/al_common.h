@@ -8,6 +8,51 @@
 
 #include "../../include/audiblelight_hip.h"
 
+// ------------------------------------------------------------------ schedule perturbation (TEST BUILDS ONLY: -DAL_SHAKE=<seed>)
+// The inline-asm paths of this library -- LDS-DMA with hand-counted s_waitcnt vmcnt(N), LDS-only barriers, look-ahead loads that stay
+// in flight across barriers -- are invisible to the host-emulation build the sanitizers and the differential fuzz run on.  What
+// protects them is that the result must not depend on the ORDER in which the waves of a workgroup reach their barriers.  A build with
+// AL_SHAKE = 1, 2, ... (tests/shake.py; never the product library) makes every wave sleep a wave-, workgroup- and site-dependent
+// number of cycles after every workgroup barrier of either kind, after every LDS-DMA issue and before every counted wait, so waves
+// leave each barrier out of step by up to a few hundred cycles; tests/test_gpu_shake.py asserts that every kernel family renders bit for
+// bit what the product library renders.  A missing barrier (round 4's al_quad16.h race) shows up as a mismatch there.
+#ifndef AL_SHAKE
+#define AL_SHAKE 0
+#endif
+namespace al {
+__device__ __forceinline__ void shake(int site) {
+#if AL_SHAKE && defined(__HIP_DEVICE_COMPILE__)
+  const unsigned wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned h = (wave + 1u) * 2654435761u ^ (blockIdx.x * 40503u + blockIdx.y * 9973u + blockIdx.z * 7919u + (unsigned)site * 97u + AL_SHAKE * 1013904223u);
+  h ^= h >> 15;
+  h *= 2246822519u;
+  h ^= h >> 13;
+#if AL_SHAKE == 3   /* wave 0 -- the wave that finishes block-wide reductions and publishes results -- is the LAST to move on, by about
+                       10 us: longer than a load from HBM takes, so that a wave waiting for its look-ahead loads still overtakes it */
+  const int n = (wave == 0 && (site == 102 || site == 104)) ? 48 : (int)(h & 1);   // after either kind of barrier
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+#elif AL_SHAKE == 4 /* ... and always the first */
+  const int n = wave == 0 ? 0 : 3 + (int)(h & 3);
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(3);
+#else
+  const int n = (int)(h & 7);
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(3);   // 3 x 64 cycles each: up to ~1350 cycles of skew per site
+#endif
+#else
+  (void)site;
+#endif
+}
+}  // namespace al
+#if AL_SHAKE && defined(__HIP_DEVICE_COMPILE__)
+// every __syncthreads() of the kernel sources: the same barrier, with the waves shaken out of step on both sides of it
+__device__ __forceinline__ void al_shaken_syncthreads() {
+  al::shake(101);
+  __syncthreads();
+  al::shake(102);
+}
+#define __syncthreads() al_shaken_syncthreads()
+#endif
+
 namespace al {
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N-1>)
 template <int... Is, class F>
@@ -94,7 +139,9 @@ template <bool LDS_ONLY>
 __device__ __forceinline__ void block_barrier() {
 #if defined(__HIP_DEVICE_COMPILE__)
   if constexpr (LDS_ONLY) {
+    shake(103);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    shake(104);
     return;
   }
 #endif

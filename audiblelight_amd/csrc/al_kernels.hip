@@ -480,9 +480,13 @@ __device__ __forceinline__ void glds16(const void *sbase, unsigned voff, unsigne
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+  al::shake(105);   // (test builds only, al_common.h: no memory operation, so the counted waits below are not disturbed)
 }
 template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_vm() {
+  al::shake(106);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 #endif
 
 // NL: the NL signal blocks at EACH end of the window live in LDS instead of registers.  Block jj of the window meets

@@ -63,6 +63,11 @@ class SyntheticScene:
         n_ir = int(np.prod(self.ir_shape)) if self.irs is None else self.irs.size
         return audio + n_ir * 4 + self.n_capsules * round(self.duration * self.sr) * 4
 
+    def algorithmic_bytes_full_api(self) -> int:
+        """SURVEY 8d "full-API contract": the scene-only bytes plus every event's (C, La) ``event.spatial_audio`` written once --
+        the API exposes it and the kernels do materialise it (un-scaled, in HBM; read again by the mixdown)."""
+        return self.algorithmic_bytes() + sum(len(c) for c in self.clips) * self.n_capsules * 4
+
 
 def make_scene(name: str = "cfg2", scene_index: int = 0, scale: float = 1.0, torch_device=None, **override) -> SyntheticScene:
     """White-noise clips + exponentially decaying random IRs with a unit direct tap.

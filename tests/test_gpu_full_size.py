@@ -34,6 +34,19 @@ def row_of(res, e, c):
     return np.asarray(res.memory.download(res.spatial[off: off + n]), dtype=np.float64)
 
 
+def check_every_event_against_the_oracle(sc, res):
+    """EVERY event of the full-size render meets the float64 oracle on one pseudo-random capsule row (bench.oracle_row_samples: the
+    check the bench line's `parity.rows_sampled` carries), on top of the hand-picked spot rows of each test."""
+    import bench
+
+    cols = lambda e: slice(sc.specs[e].emitter0, sc.specs[e].emitter0 + sc.specs[e].n_emitters)    # noqa: E731
+    rec = bench.oracle_row_samples(sc, res, range(len(sc.specs)), lambda e, c: sc.irs[c, cols(e), :],
+                                   lambda e: orc.emitter_gains(sc.irs[:, cols(e), :]))
+    assert rec["events"] == len(sc.specs) and rec["ok"], {k: v for k, v in rec.items() if k != "note"}
+    assert rec["rel_rms_worst_row"] <= TOL and rec["max_abs_over_peak_worst_row"] <= TOL
+    return rec
+
+
 def check_level_invariant(sc, res):
     """A9 on EVERY event: mean|scale * x| over (C, La) equals 10^((ref_db + snr)/20); and nothing is non-finite."""
     res.check_finite()
@@ -103,6 +116,7 @@ def test_cfg3_full_size_moving_sources(gpu):
         want = orc.fit_length(orc.convolve_moving(sc.clips[e], sel, sp.duration, sc.sr), sp.n_samples)
         for i, c in enumerate(caps):
             assert_parity(row_of(res, e, c), want[i], TOL, what=(e, c))
+    assert check_every_event_against_the_oracle(sc, res)["events"] == 16
     check_scene_row(gpu, planning, sc, pl, res, scales, c=11)
 
 
@@ -127,6 +141,7 @@ def test_cfg5_full_size_64ch_ambience_folded_fx(gpu):
         assert gains[e] == pytest.approx(g_ref, rel=2e-5)
         want = fftconvolve(clip.astype(np.float64), sc.irs[c, e].astype(np.float64))[: sc.specs[e].n_samples] * g_ref
         assert_parity(row_of(res, e, c), want, TOL, what=(e, c))
+    assert check_every_event_against_the_oracle(sc, res)["events"] == 128
     a = amb.Ambience(channels=64, duration=sc.duration, alias="full", noise="white", ref_db=-65, sample_rate=sc.sr, rng="device", seed=7)
     n_scene = round(sc.duration * sc.sr)
     pair = _ambience_on_device(gpu, a, (64, n_scene))

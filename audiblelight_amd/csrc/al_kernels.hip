@@ -1794,13 +1794,16 @@ int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t w
 
 int al_tv_stft_mac(const float *s_audio, const float *s_ir, const float *w_ir, int32_t n_frames, int32_t n_frames_ir,
                    int32_t n_freq, int32_t n_ch, int32_t n_irs, float *out, al_stream_t stream) {
-  if (!s_audio || !s_ir || !w_ir || !out || n_frames <= 0 || n_frames_ir <= 0 || n_freq <= 0 || n_ch <= 0 || n_irs <= 0 ||
-      n_frames > 65535)
+  if (!s_audio || !s_ir || !w_ir || !out || n_frames <= 0 || n_frames_ir <= 0 || n_freq <= 0 || n_ch <= 0 || n_irs <= 0)
     return fail(AL_E_BADARG, "bad tv_stft_mac arguments");
-  const dim3 grid((unsigned)(((int64_t)n_freq * n_ch + 255) / 256), n_frames);
-  hipLaunchKernelGGL(al::k_tv_stft_mac, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2 *>(s_audio),
-                     reinterpret_cast<const float2 *>(s_ir), w_ir, n_frames, n_frames_ir, n_freq, n_ch, n_irs,
-                     reinterpret_cast<float2 *>(out));
+  // one launch per MAX_GRID_ROWS output frames (grid.y limit): a clip of any length (hop 16 at 44.1 kHz passes 65 535 frames after 23 s)
+  for (int32_t f0 = 0; f0 < n_frames; f0 += MAX_GRID_ROWS) {
+    const int g = n_frames - f0 < MAX_GRID_ROWS ? n_frames - f0 : MAX_GRID_ROWS;
+    const dim3 grid((unsigned)(((int64_t)n_freq * n_ch + 255) / 256), g);
+    hipLaunchKernelGGL(al::k_tv_stft_mac, grid, dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const float2 *>(s_audio),
+                       reinterpret_cast<const float2 *>(s_ir), w_ir, f0, n_frames_ir, n_freq, n_ch, n_irs,
+                       reinterpret_cast<float2 *>(out));
+  }
   return check_launch("k_tv_stft_mac");
 }
 

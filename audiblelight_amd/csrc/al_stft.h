@@ -41,9 +41,9 @@ __global__ __launch_bounds__(256) void k_stft_take_half(const float2 *__restrict
 // out[i][f][c] = sum_{k=0}^{min(i, F_ir-1)} S[i-k][f] * sum_l W[i-k][l] * H[k][f][c][l]     (synthesize.py:217-250)
 // one thread per (f, c) of one output frame i; layouts as the reference's arrays (C order).
 __global__ __launch_bounds__(256) void k_tv_stft_mac(const float2 *__restrict__ s_audio, const float2 *__restrict__ s_ir,
-                                                     const float *__restrict__ w, int n_frames, int n_frames_ir, int n_freq,
+                                                     const float *__restrict__ w, int frame0, int n_frames_ir, int n_freq,
                                                      int n_ch, int n_irs, float2 *__restrict__ out) {
-  const int i = blockIdx.y;
+  const int i = frame0 + blockIdx.y;           // launches cover the frame axis in groups of the grid's y limit
   const int fc = blockIdx.x * 256 + threadIdx.x;
   if (fc >= n_freq * n_ch) return;
   const int f = fc / n_ch;

@@ -32,10 +32,12 @@ def shard_stream(items, rank: int, world_size: int):
 def host_share(local_rank: int, local_world: int, device_index: Optional[int] = None, pin: bool = True) -> dict:
     """This rank's share of the host: N ranks on one node must not each size their helper pools (IR cast threads, clip packers,
     the batch driver's planner / uploader / writer) for the whole machine.  Returns {"cpus": usable CPUs of this rank,
-    "threads": the cap for any one pool, "numa_node", "pinned"}.  With ``pin`` the process is restricted (sched_setaffinity) to
-    the CPUs local to its GPU's NUMA node (sysfs ``local_cpulist`` of the GPU's PCI function) when the node can be found --
-    H2D staging and page-locked buffers then live next to the GPU -- else to an equal contiguous slice of the usable CPUs.
-    Best effort: any failure leaves the affinity alone and only the cap applies."""
+    "threads": the cap for any one pool, "numa_node", "pinned", "threads_pinned"}.  With ``pin`` the process is restricted
+    (sched_setaffinity) to the CPUs local to its GPU's NUMA node (sysfs ``local_cpulist`` of the GPU's PCI function) when the node
+    can be found -- H2D staging and page-locked buffers then live next to the GPU -- else to an equal contiguous slice of the usable
+    CPUs.  The mask is applied to EVERY thread that exists at the time (/proc/self/task: sched_setaffinity(0, ...) alone would only
+    move the calling thread; torch / OpenMP workers, RCCL proxies and upload helpers started earlier would keep the whole machine),
+    threads created later inherit it.  Best effort: any failure leaves the affinity alone and only the cap applies."""
     import os
 
     try:
@@ -70,7 +72,19 @@ def host_share(local_rank: int, local_world: int, device_index: Optional[int] = 
             os.sched_setaffinity(0, mine)
             out["pinned"], out["cpus"] = True, len(mine)
         except (AttributeError, OSError):
-            pass
+            return out
+        moved = 0
+        try:
+            tids = [int(t) for t in os.listdir("/proc/self/task")]
+        except OSError:
+            tids = []
+        for tid in tids:          # on Linux sched_setaffinity takes a thread id: every thread of this process, not only the caller
+            try:
+                os.sched_setaffinity(tid, mine)
+                moved += 1
+            except OSError:       # a thread that exited meanwhile
+                pass
+        out["threads_pinned"] = moved
     return out
 
 

@@ -444,14 +444,16 @@ class Renderer:
 
     def prepare(self, plan: BatchPlan, clips: Sequence[np.ndarray], irs, ir_strides=None,
                 chunk_events: Optional[int] = None, normalize_irs: bool = True, lanes: int = 1,
-                audio_dev=None, emitter_parts: Optional[np.ndarray] = None) -> "PreparedBatch":
+                audio_dev=None, emitter_parts: Optional[np.ndarray] = None, spectra_workspaces: bool = True) -> "PreparedBatch":
         """Upload inputs + tables and allocate every workspace/output buffer of one batch.
         ``irs`` is a (C, N, L) ndarray or a device buffer from upload_irs (then pass ``ir_strides``).
         ``chunk_events``: run the batch as chunks of that many events over a reused spectra workspace.
         ``lanes``: number of workspaces / HIP streams the chunks alternate over (chunk i runs on lane i % lanes),
         so the HBM-bound accumulate of one chunk can overlap the instruction-bound transforms of another.
         ``emitter_parts``: the caller's own al_batch.emitter_parts (int32 per IR column; 0 = "energies only": the forward transform
-        reads that IR for normalize_irs and neither transforms nor stores it) instead of the planner's."""
+        reads that IR for normalize_irs and neither transforms nor stores it) instead of the planner's.
+        ``spectra_workspaces=False``: a batch that will only run the IR energy pass and the level law (the general STFT path of
+        synthesize._render_moving_general): the H / X / Y spectra workspaces are one block each instead of the batch's size."""
         mem = self.mem
         on_its_way = irs if hasattr(irs, "result") else None      # from upload_irs_beside: waited for below, after the staging
         if ir_strides is None and on_its_way is None:   # a host tensor (with ir_strides: a device buffer from upload_irs / ingest.pack_ragged_irs)
@@ -464,6 +466,8 @@ class Renderer:
         h_blocks = max(max(c["n_emitters"] for c in chunks) * C * P, 1)
         x_blocks = max(max(c["xspec_blocks"] for c in chunks), 1)
         y_blocks = max(max(c["yspec_blocks"] for c in chunks), 1)
+        if not spectra_workspaces:
+            h_blocks = x_blocks = y_blocks = 1
         lanes = max(1, min(int(lanes), len(chunks)))
         sources = [as_clip_source(c) for c in clips]
         if audio_dev is None:

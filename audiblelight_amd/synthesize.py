@@ -94,6 +94,19 @@ def _check_geometry(fft_size: int, win_size: int, hop_size: int) -> None:
                          f"overlap-add buffer, fft_size must be at most 2*hop_size + win_size = {2 * hop_size + win_size}")
 
 
+def _check_general_geometry(fft_size: int, n_audio: int, hop_size: int) -> None:
+    """What the literal STFT chain of THIS build cannot transform, said before anything is uploaded (the reference renders these;
+    here they would surface as a HipError from inside the chain): al_stft / al_istft_ola take fft sizes that factor into 2, 3, 5
+    and 7 (the mixed-radix passes of csrc/al_bigfft.h)."""
+    m = int(fft_size)
+    for p in (2, 3, 5, 7):
+        while m % p == 0:
+            m //= p
+    if m != 1:
+        raise ValueError(f"fft_size = {fft_size} is not supported by this build for STFT geometries outside win = 2 * hop, fft >= 2 * win - 1: "
+                         f"it must factor into 2, 3, 5 and 7 (largest other factor: {m})")
+
+
 def _permuted(buf, shape, axes):
     """A contiguous device copy of ``buf`` viewed as ``shape`` with its axes permuted (a copy, no arithmetic)."""
     n = int(np.prod(shape))
@@ -130,18 +143,18 @@ def _tv_chain_on_device(r, ir_dev, n_ch: int, n_irs: int, ir_len: int, audio_dev
         return mem.zeros(1), 0
     rows = n_ch * n_irs
     h_spec = mem.empty(2 * rows * f_ir * n_freq)
-    work = mem.empty(lib.call("al_stft_workspace_floats", rows * f_ir, fft_size))
+    # ONE workspace for the three transforms (stream-ordered: each is done with it before the next starts)
+    work = mem.empty(max(lib.call("al_stft_workspace_floats", rows * f_ir, fft_size), lib.call("al_stft_workspace_floats", f_a, fft_size),
+                         lib.call("al_istft_workspace_floats", n_frames, n_ch, fft_size)))
     lib.call("al_stft", mem.ptr(ir_dev), rows, ir_len, fft_size, win_size, hop_size, mem.ptr(h_spec), mem.ptr(work), st)
     s_ir = _permuted(h_spec, (n_ch, n_irs, f_ir, n_freq, 2), (2, 3, 0, 1, 4))      # (F_ir, freq, C, N): the reference's layout
     del h_spec
     a_spec = mem.empty(2 * f_a * n_freq)
-    work = mem.empty(lib.call("al_stft_workspace_floats", f_a, fft_size))
     lib.call("al_stft", mem.ptr(audio_dev), 1, n_audio, fft_size, win_size, hop_size, mem.ptr(a_spec), mem.ptr(work), st)
     w_dev = mem.upload(np.ascontiguousarray(w, dtype=np.float32).reshape(-1))
     y = mem.empty(2 * n_frames * n_freq * n_ch)
     lib.call("al_tv_stft_mac", mem.ptr(a_spec), mem.ptr(s_ir), mem.ptr(w_dev), n_frames, f_ir, n_freq, n_ch, n_irs, mem.ptr(y), st)
     out = mem.empty(n_out * n_ch)
-    work = mem.empty(lib.call("al_istft_workspace_floats", n_frames, n_ch, fft_size))
     lib.call("al_istft_ola", mem.ptr(y), n_frames, n_freq, n_ch, fft_size, win_size, hop_size, mem.ptr(out), mem.ptr(work), st)
     return out, n_out
 
@@ -159,6 +172,7 @@ def time_variant_convolution(irs: np.ndarray, event, fft_size=config.FFT_SIZE, w
     _check_geometry(fft_size, win_size, hop_size)
     n_ch, n_irs, n_ir = irs.shape
     if not _envelope_geometry(fft_size, win_size, hop_size):
+        _check_general_geometry(fft_size, len(audio), hop_size)
         r = get_renderer()
         ir_dev = r.mem.upload(np.ascontiguousarray(irs, dtype=np.float32).reshape(-1))
         out, n_out = _tv_chain_on_device(r, ir_dev, n_ch, n_irs, n_ir, r.mem.upload(np.ascontiguousarray(audio)), len(audio),
@@ -442,16 +456,23 @@ def _render_moving_general(r: engine.Renderer, spec, clip, irs: np.ndarray, fft_
     n_ch, n_irs, n_ir = irs.shape
     host_clip = engine.as_clip_source(clip)
     pl = planning.plan_batch([spec], n_ch, n_ir, sample_rate, lib=lib)          # layout + tables only (default geometry)
-    # emitter_parts = 0 everywhere: the forward pass only takes the IR energies (normalize_irs), no partition spectrum is made
-    batch = r.prepare(pl, [clip], irs, emitter_parts=np.zeros(n_irs, dtype=np.int32))
+    # emitter_parts = 0 everywhere: the IR pass only takes the energies (normalize_irs); no partition spectrum, signal spectrum or
+    # output spectrum is ever made on this path, so those workspaces are one block each
+    batch = r.prepare(pl, [clip], irs, emitter_parts=np.zeros(n_irs, dtype=np.int32), spectra_workspaces=False)
     desc = batch.descs[0]
-    for name in ("al_forward_spectra", "al_emitter_gains"):
+    for name in ("al_ir_spectra", "al_emitter_gains"):
         lib.call(name, ct.byref(desc), st)
     bufs = batch.bufs
     pitch = int(desc.ir_stride_n)
-    gains = mem.ptr(bufs["emitter_gain"])
-    for c in range(n_ch):      # h[c, n, :] *= g[n]: one launch per capsule over its (N, pitch) rows
-        lib.call("al_scale_matrix_rows", mem.ptr(bufs["ir"]) + 4 * c * int(desc.ir_stride_c), n_irs, pitch, gains, st)
+    gains = bufs["emitter_gain"][:n_irs]
+    if int(desc.ir_stride_c) == n_irs * pitch:     # the (C * N) rows are evenly spaced: h[c, n, :] *= g[n] as ONE launch per 65 535 rows
+        tiled = gains.repeat(n_ch) if hasattr(gains, "repeat") and not isinstance(gains, np.ndarray) else np.tile(gains, n_ch)
+        for r0 in range(0, n_ch * n_irs, 65535):
+            nr = min(65535, n_ch * n_irs - r0)
+            lib.call("al_scale_matrix_rows", mem.ptr(bufs["ir"]) + 4 * r0 * pitch, nr, pitch, mem.ptr(tiled) + 4 * r0, st)
+    else:
+        for c in range(n_ch):      # a capsule pitch of its own: one launch per capsule over its (N, pitch) rows
+            lib.call("al_scale_matrix_rows", mem.ptr(bufs["ir"]) + 4 * c * int(desc.ir_stride_c), n_irs, pitch, mem.ptr(gains), st)
     n_audio = len(host_clip)
     audio_dev = bufs["audio"]      # the clip as uploaded (a finished clip: event.load_audio()'s peak-normalised array)
     if bufs.get("clip_scale") is not None:   # folded scalar FX / device-side peak normalisation: applied to a copy of the clip
@@ -493,6 +514,7 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
     if n_emitters > 1:
         _check_geometry(fft_size, win_size, hop_size)
     if n_emitters > 1 and not _envelope_geometry(fft_size, win_size, hop_size):
+        _check_general_geometry(fft_size, len(clip), hop_size)
         res = _render_moving_general(r, spec, clip, irs, fft_size, win_size, hop_size, float(event.sample_rate))
     else:
         geometry = dict(hop=hop_size, win=win_size, fft_size=fft_size) if n_emitters > 1 else {}   # static / tiled events never frame

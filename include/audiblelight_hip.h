@@ -319,7 +319,7 @@ int64_t al_stft_workspace_floats(int64_t series /* rows * n_frames */, int32_t f
 int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t win_size, int32_t hop_size, float *spec,
             float *workspace, al_stream_t stream);
 /* perform_time_variant_convolution (synthesize.py:184-252): s_audio (F_a, n_freq), s_ir (F_ir, n_freq, n_ch, n_irs)
- * complex64, w_ir (F_w, n_irs) float32 -> out (n_frames, n_freq, n_ch) complex64, n_frames = min(F_a, F_w) <= 65535. */
+ * complex64, w_ir (F_w, n_irs) float32 -> out (n_frames, n_freq, n_ch) complex64, n_frames = min(F_a, F_w) (any count: launched in groups of frames). */
 int al_tv_stft_mac(const float *s_audio, const float *s_ir, const float *w_ir, int32_t n_frames, int32_t n_frames_ir,
                    int32_t n_freq, int32_t n_ch, int32_t n_irs, float *out, al_stream_t stream);
 /* istft_overlap_synthesis (synthesize.py:255-274): spatial_stft (n_frames, n_freq, n_ch) complex64 -> out

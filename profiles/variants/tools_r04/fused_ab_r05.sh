@@ -1,3 +1,5 @@
+# NOTE (round 6): reads AL_FUSED / AL_FUSED_MOVING, which left the library in commit 4b1d6c4: check out 4b1d6c4^ to reproduce
+# profiles/r05c_fused_ab.txt; on a later tree both arms run the same kernels.
 # Round 5, the time-boxed decision on the two opt-in fused kernels: same box, alternating, per-scene time.
 #   k_mac_synthesis (csrc/al_fused.h, AL_FUSED=1)  on cfg4 (P = 6: the regime where its H / X re-reads per output block are smallest) and cfg2
 #   k_moving_fused  (csrc/al_quad.h, AL_FUSED_MOVING=1) on cfg3

@@ -55,9 +55,18 @@ WORKER = textwrap.dedent("""
         for i in range(3):
             np.testing.assert_array_equal(got[i].numpy(), render(i, r, equal=True))
     # this rank's share of the host: half the usable CPUs as the cap of any helper pool, and the process pinned to its half
+    import threading
     before = len(os.sched_getaffinity(0))
+    parked, tid = threading.Event(), []
+    helper = threading.Thread(target=lambda: (tid.append(threading.get_native_id()), parked.wait()))   # a thread that exists BEFORE
+    helper.start()
+    while not tid:
+        pass
     share = distributed.host_share(rank, 2, None, pin=True)
     assert share["threads"] == max(1, before // 2) and share["pinned"] and len(os.sched_getaffinity(0)) == share["cpus"] == max(1, before // 2)
+    # ... and so is every thread that already existed (gloo's, torch's, this helper): sched_setaffinity(0, ...) alone moves only the caller
+    assert share["threads_pinned"] >= 2 and os.sched_getaffinity(tid[0]) == os.sched_getaffinity(0)
+    parked.set()
     dist.destroy_process_group()
 """)
 

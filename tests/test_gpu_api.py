@@ -38,6 +38,7 @@ test_scene_generate_argument_list = scenarios.test_scene_generate_argument_list
 test_stft_helpers_match_reference = scenarios.test_stft_helpers_match_reference
 test_moving_events_under_other_stft_geometries = scenarios.test_moving_events_under_other_stft_geometries
 test_degenerate_events_render_like_the_reference = scenarios.test_degenerate_events_render_like_the_reference
+test_general_stft_path_limits = scenarios.test_general_stft_path_limits
 test_fx_chain_stays_on_device_and_scalars_fold = scenarios.test_fx_chain_stays_on_device_and_scalars_fold
 test_reference_format_scene_json_renders_like_the_reference = scenarios.test_reference_format_scene_json_renders_like_the_reference
 test_ir_ingest_ragged_packing_and_resampling = scenarios.test_ir_ingest_ragged_packing_and_resampling

@@ -467,6 +467,39 @@ def test_moving_events_under_other_stft_geometries():
     assert r is syn.get_renderer()
 
 
+def test_general_stft_path_limits():
+    """Advisor r05: the literal STFT chain behind non-default geometries.  More output frames than one launch's grid holds
+    (hop 16 at 44.1 kHz passes 65 535 frames after 23 s of clip): al_tv_stft_mac walks the frame axis in groups -- 70 000 frames here
+    against the defining sum (synthesize.py:217-250).  An fft size the mixed-radix transforms of this build do not take is refused
+    with a ValueError that names it BEFORE anything is uploaded, from render_event_audio and from time_variant_convolution alike."""
+    rng = np.random.default_rng(5)
+    n_frames, f_ir, n_freq, n_ch, n_irs = 70_000, 2, 2, 1, 2
+    s_a = (rng.standard_normal((n_frames, n_freq)) + 1j * rng.standard_normal((n_frames, n_freq))).astype(np.complex64)
+    s_ir = (rng.standard_normal((f_ir, n_freq, n_ch, n_irs)) + 1j * rng.standard_normal((f_ir, n_freq, n_ch, n_irs))).astype(np.complex64)
+    w = rng.random((n_frames, n_irs)).astype(np.float32)
+    got = syn.perform_time_variant_convolution(s_a, s_ir, w)
+    ctf = np.einsum("il,kfcl->ikfc", w.astype(np.float64), s_ir.astype(np.complex128))        # (i, k, f, c)
+    want = s_a[:, :, None] * ctf[:, 0]
+    want[1:] += s_a[:-1, :, None] * ctf[:-1, 1]
+    assert got.shape == (n_frames, n_freq, n_ch)
+    assert np.abs(got - want).max() < 1e-5 * np.abs(want).max() and np.abs(got[-1]).max() > 0      # the last group was written too
+
+    import types
+
+    a = rng.standard_normal(3000).astype(np.float32)
+    a /= np.abs(a).max()
+    h = rng.standard_normal((2, 3, 200)).astype(np.float32)
+    ev = types.SimpleNamespace(alias="m", snr=7.0, sample_rate=8000, is_moving=True, duration=3000 / 8000, spatial_audio={},
+                               _spatial_audio_dry={}, ref_ir_channel=None, direct_path_time_ms=None,
+                               load_audio=lambda ignore_cache=False, normalize=True: a, __len__=lambda: 3)
+    for call in (lambda: syn.render_event_audio(ev, h, "m", fft_size=22, win_size=12, hop_size=5),
+                 lambda: syn.time_variant_convolution(h, ev, fft_size=22, win_size=12, hop_size=5)):
+        with pytest.raises(ValueError, match="fft_size = 22 is not supported by this build.*largest other factor: 11"):
+            call()
+    syn.render_event_audio(ev, h, "m", fft_size=20, win_size=12, hop_size=5)      # 20 = 2^2 * 5: the same geometry class renders
+    assert np.isfinite(ev.spatial_audio["m"]).all() and ev.spatial_audio["m"].shape == (2, 3000)
+
+
 def test_degenerate_events_render_like_the_reference():
     """Silence stays silence (G15: the reference's own renders of degenerate events): snr = 0, a negative snr, an all-zero IR, an
     all-zero clip, a moving event with one all-zero IR among its emitters, the dry render of an all-zero clip.  The reference forms

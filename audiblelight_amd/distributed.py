@@ -280,8 +280,11 @@ def prepare_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total
 
 
 def run_capsule_sharded(renderer, batch, total_capsules: int, timers: Optional[dict] = None):
-    """One pass of a prepared capsule-sharded batch: only enqueues (kernels and two stream-ordered collectives on DEVICE
-    arrays; nothing is copied to the host and nothing waits).  ``timers``: a dict that receives ``(start, end)`` event
+    """One pass of a prepared capsule-sharded batch: only enqueues (kernels and two stream-ordered EXCHANGES on DEVICE arrays =
+    three all-reduce calls: the IR norm sums (SUM), then the level statistics as one SUM and one MAX call, since a collective has
+    one reduction operator; nothing is copied to the host and nothing waits).  Every ``al_*`` launch goes to torch's current
+    stream and ``dist.all_reduce`` (async_op=False) makes that stream wait for the collective, so kernels and collectives are
+    ordered on the device without a host synchronisation.  ``timers``: a dict that receives ``(start, end)`` event
     pairs around each collective (``make_event()`` from the caller under key "make_event"), for bench.py."""
     import ctypes as ct
 
@@ -332,8 +335,9 @@ def render_capsule_sharded(renderer, specs, clips, irs_local: np.ndarray, total_
 
     Every rank convolves all events against its own capsule rows of the IR tensor (clips are replicated: small).
     The per-event level (one scalar from sum|x| and max|x| over ALL capsules, synthesize.py:594-599) is the
-    only coupling: one all-reduce of E x {SUM, MAX, SUM} doubles between block synthesis and the level law
-    (plus the per-emitter IR norm sums of normalize_irs, synthesize.py:404-428, before the accumulate).
+    only coupling: E x {sum|x|, #non-finite} (one SUM all-reduce) and E x max|x| (one MAX all-reduce) between block
+    synthesis and the level law (plus the per-emitter IR norm sums of normalize_irs, synthesize.py:404-428, one SUM
+    all-reduce before the accumulate): three small all-reduce calls per scene.
     Returns the RenderResult of the local capsules (event_scale identical on every rank).
     """
     batch = prepare_capsule_sharded(renderer, specs, clips, irs_local, total_capsules, sample_rate, log2_block)

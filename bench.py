@@ -18,7 +18,7 @@ pass of K steps right behind them.
 
 Other modes: `--total-scenes S` (cfg4: S scenes split over the ranks, every one rendered and ALL of them
 gathered on rank 0: strong scaling), `--shard capsules` (cfg5: ONE scene, its capsules split over the
-ranks, two all-reduces of per-emitter / per-event scalars inside the step).
+ranks, two exchanges (three all-reduce calls) of per-emitter / per-event scalars inside the step).
 """
 import argparse
 import json
@@ -1387,7 +1387,7 @@ def run_scene_batch_mode(ctx):
 
 def run_capsule_sharded_mode(ctx):
     """SURVEY 8e row 2 / cfg5 secondary: ONE scene per step, rank r owns capsule rows capsule_slice(C, r, N) of every event;
-    the only exchanges are two all-reduces of per-emitter / per-event scalars on device arrays (timed separately); every
+    the only exchanges are two (three all-reduce calls: SUM, SUM, MAX) of per-emitter / per-event scalars on device arrays (timed separately); every
     rank mixes its own rows.  After the timed region the rows are gathered on rank 0 and compared with rank 0's own render
     of the WHOLE scene (float32 rounding of the level law's partial sums: tolerance, not bit-exactness)."""
     args, rank, world, emulate, torch = ctx["args"], ctx["rank"], ctx["world"], ctx["emulate"], ctx["torch"]

@@ -1,6 +1,6 @@
 """Regenerate the two result tables of DESIGN.md (section 5 kernel table, section 7 config table) from the round's profile files:
 profiles/<TAG>_cfgN_kernel_stats.csv, profiles/pmc_traffic.json, profiles/<TAG>_bench_cfgN.json.
-    python3 profiles/tools/design_tables.py [TAG]        (default r05)
+    python3 profiles/tools/design_tables.py [TAG]        (default r06)
 The tables sit between the markers <!-- kernel-table --> / <!-- /kernel-table --> and <!-- results-table --> / <!-- /results-table -->
 (a fresh DESIGN.md carries @@KERNEL_TABLE@@ / @@RESULTS_TABLE@@ instead)."""
 import csv
@@ -10,7 +10,7 @@ import re
 import sys
 
 R = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r06"
 p = os.path.join(R, "DESIGN.md")
 s = open(p).read()
 t = json.load(open(os.path.join(R, "profiles", "pmc_traffic.json")))
@@ -64,14 +64,27 @@ rows.append("| `k_emitter_gains` + `k_event_levels` | " + " | ".join(f"{k[c]['al
 rows.append("| scene: bench `ms_per_step` (median of 3 × K steps; the pool's boxes differ by about 3 %), PMC bytes | "
             + " | ".join(f"**{d[c]['ms_per_step']:.2f} ms**, {tot[c]:.1f} GB" for c in CFGS) + " |")
 alg = {c: d[c]["roofline"]["algorithmic_bytes_per_launch"] / 1e9 for c in CFGS}
-rows.append("| algorithmic bytes (SURVEY 8d); `roofline.frac` / `path_frac`; `traffic_ratio` | "
+rows.append("| algorithmic bytes, scene-only contract (SURVEY 8d: inputs + `scene.audio`); `roofline.frac` / `path_frac`; `traffic_ratio` | "
             + " | ".join(f"{alg[c]:.3f} GB; {d[c]['roofline']['frac']:.3f} / {d[c]['roofline']['path_frac']:.3f}; {tot[c] / alg[c]:.1f}×" for c in CFGS) + " |")
+full = {c: d[c]["roofline"].get("contracts", {}).get("full_api") for c in CFGS}
+if all(full.values()):
+    rows.append("| ... full-API contract (+ every `event.spatial_audio` written once); `frac` / `path_frac`; `traffic_ratio` | "
+                + " | ".join(f"{full[c]['algorithmic_bytes'] / 1e9:.3f} GB; {full[c]['frac']:.3f} / {full[c]['path_frac']:.3f}; "
+                             f"{tot[c] / (full[c]['algorithmic_bytes'] / 1e9):.1f}×" for c in CFGS) + " |")
 kernel_table = "<!-- kernel-table -->\n" + "\n".join(rows) + "\n<!-- /kernel-table -->"
 
 
 def parity_of(c):
     par = d[c].get("parity")
-    return f"{par['rel_rms']:.1e} / {par['max_abs_over_peak']:.1e} ({par['events']} events, {par['rows']} × {fmt(par['samples'])})" if par else "—"
+    if not par:
+        return "—"
+    full = par.get("events_in_full", par["events"])
+    txt = f"{par['rel_rms']:.1e} / {par['max_abs_over_peak']:.1e} ({full} event{'s' if full != 1 else ''} in full, {par['rows']} × {fmt(par['samples'])}"
+    rs = par.get("rows_sampled")
+    if rs:
+        txt += (f"; one row of each of the other {rs['events']}: worst {rs['rel_rms_worst_row']:.1e} / {rs['max_abs_over_peak_worst_row']:.1e}, "
+                f"level invariant within {rs['level_invariant_worst_rel_err']:.0e}")
+    return txt + ")"
 
 
 def cpu_of(c):
@@ -97,7 +110,7 @@ tail = ""
 if e2e and drop:
     tail = (f"\n\nPCIe-inclusive on the same run (never the headline): pipelined batch driver **{fmt(e2e['value'])} scene-s/s** "
             f"({e2e['ms_per_scene']:.1f} ms per cfg2 scene), synchronous drop-in `Scene.generate()` **{fmt(drop['value'])}** ({drop['ms_per_scene']:.1f} ms).")
-results_table = (f"<!-- results-table -->\nRound-5 results (`profiles/{TAG}_bench_*.json`: one MI355X, host {d['cfg2']['cpu_baseline']['cpu_model']}, final sources "
+results_table = (f"<!-- results-table -->\nRound-{int(TAG[1:3])} results (`profiles/{TAG}_bench_*.json`: one MI355X, host {d['cfg2']['cpu_baseline']['cpu_model']}, final sources "
                  f"`{d['cfg2']['config']['source_hash']}`; kernel rows in section 5):\n\n" + "\n".join(res) + tail + "\n<!-- /results-table -->")
 
 for marker, block, tag in (("@@KERNEL_TABLE@@", kernel_table, "kernel-table"), ("@@RESULTS_TABLE@@", results_table, "results-table")):

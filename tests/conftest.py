@@ -60,7 +60,7 @@ def pcm16(x):
 # ----------------------------------------------------------------------------- the contract's parity metric, with margins
 # SURVEY.md 8(d) "Parity metric": per scene and per event rms(y - y_ref) / rms(y_ref) <= 1e-4 AND
 # max|y - y_ref| <= 1e-4 * max|y_ref|, y_ref = the float64 oracle.  Every GPU test asserts BOTH through assert_parity;
-# the worst observed pair per test module is written to gpurun_out/r05_parity_margins.txt at the end of the session
+# the worst observed pair per test module is written to gpurun_out/r06_parity_margins.txt at the end of the session
 # (copied to profiles/ by hand: gpurun_out/ is scratch).
 PARITY_TOL = 1e-4
 _MARGINS = {}
@@ -94,7 +94,7 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         os.makedirs(out_dir, exist_ok=True)
         worker = os.environ.get("PYTEST_XDIST_WORKER")
-        name = "r05_parity_margins" + (f"_{worker}" if worker else "") + ".txt"
+        name = "r06_parity_margins" + (f"_{worker}" if worker else "") + ".txt"
         with open(os.path.join(out_dir, name), "w") as fh:
             fh.write("# worst observed parity errors per test module (tests/conftest.py::assert_parity); contract: both <= 1e-4\n")
             fh.write("# module                              comparisons   worst rel. RMS   worst max|err| / max|ref|\n")

@@ -1761,14 +1761,42 @@ int al_axpy_rows(float *y, const float *x, const float *a_dev, int32_t rows, int
 
 // ---- STFT-domain intermediates of the moving path (A7), reference signatures kept in audiblelight_amd/synthesize.py
 namespace {
-bool smooth_length(int64_t n) { return n > 0 && strip_small_factors(n) == 1; }
 constexpr int64_t MAX_GRID_ROWS = 32768;  // series per launch group (grid.y limit is 65535)
+
+// Complex FFT of `rows` series of `len` points for ANY len (the reference's numpy rfft / irfft take any fft_size, synthesize.py:135,263):
+// Stockham passes where len factors into 2, 3, 5 and 7, Bluestein's chirp-z on a power-of-two length otherwise (the pieces of
+// al_bigfft.h the ambience synthesis uses).  `x` holds the input, `y` is a second rows x len buffer, `tmp` any_fft_tmp_floats(rows, len)
+// floats (none for smooth lengths).  Returns the buffer that holds the transform (x or y; always y on the Bluestein path).
+int64_t bluestein_length(int64_t len) {
+  int64_t L = 1;
+  while (L < 2 * len - 1) L <<= 1;
+  return L;
+}
+int64_t any_fft_tmp_floats(int64_t rows, int64_t len) {
+  if (strip_small_factors(len) == 1) return 0;
+  const int64_t L = bluestein_length(len);
+  return 2 * (2 * rows * L + 2 * L);   // two rows x L ping-pong buffers, the chirp kernel and its partner
+}
+const float2 *any_fft(float2 *x, float2 *y, float *tmp, int rows, int64_t len, int dir, hipStream_t st) {
+  if (strip_small_factors(len) == 1) return big_fft(x, y, rows, len, dir, st);
+  const int64_t L = bluestein_length(len);
+  float2 *a = reinterpret_cast<float2 *>(tmp), *b = a + (int64_t)rows * L, *kern = b + (int64_t)rows * L;
+  const dim3 g_len((unsigned)((len + 255) / 256), rows), g_L((unsigned)((L + 255) / 256), rows), g_L1((unsigned)((L + 255) / 256), 1);
+  hipLaunchKernelGGL(al::k_blue_kernel, g_L1, dim3(256), 0, st, len, L, dir, kern);
+  const float2 *kspec = big_fft(kern, kern + L, 1, L, -1, st);
+  hipLaunchKernelGGL(al::k_blue_pre, g_L, dim3(256), 0, st, (const float2 *)x, len, L, dir, a);
+  float2 *A = big_fft(a, b, rows, L, -1, st);
+  hipLaunchKernelGGL(al::k_blue_mul, g_L, dim3(256), 0, st, A, kspec, L);
+  const float2 *conv = big_fft(A, (A == a) ? b : a, rows, L, +1, st);
+  hipLaunchKernelGGL(al::k_blue_post, g_len, dim3(256), 0, st, conv, len, L, dir, y);
+  return y;
+}
 }  // namespace
 
 int64_t al_stft_workspace_floats(int64_t series, int32_t fft_size) {
   if (series <= 0 || fft_size <= 0) return 0;
   const int64_t group = series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS;
-  return 2 * 2 * group * (int64_t)fft_size;  // ping-pong complex buffers for one launch group
+  return 2 * 2 * group * (int64_t)fft_size + any_fft_tmp_floats(group, fft_size);  // ping-pong complex buffers for one launch group (+ Bluestein's)
 }
 
 int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t win_size, int32_t hop_size, float *spec,
@@ -1776,17 +1804,18 @@ int al_stft(const float *y, int64_t rows, int64_t n, int32_t fft_size, int32_t w
   // fft_size < win_size is legal in the reference: rfft(frames, n=fft_size) crops every windowed frame to its first fft_size samples
   if (!y || !spec || !workspace || rows <= 0 || n <= 0 || win_size <= 0 || hop_size <= 0 || win_size < hop_size || fft_size <= 0)
     return fail(AL_E_BADARG, "bad stft arguments");
-  if (!smooth_length(fft_size)) return fail(AL_E_UNSUPPORTED, "stft: fft_size must factor into 2, 3, 5, 7");
   hipStream_t st = (hipStream_t)stream;
   const int n_frames = 2 * (int)((n + 2 * (int64_t)hop_size - 1) / (2 * (int64_t)hop_size)) + 1;
   const int64_t series = rows * n_frames;
+  const int64_t group = series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS;
   float2 *a = reinterpret_cast<float2 *>(workspace);
+  float2 *b = a + group * fft_size;
+  float *tmp = reinterpret_cast<float *>(b + group * fft_size);
   for (int64_t s0 = 0; s0 < series; s0 += MAX_GRID_ROWS) {
     const int g = (int)(series - s0 < MAX_GRID_ROWS ? series - s0 : MAX_GRID_ROWS);
-    float2 *b = a + (int64_t)(series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS) * fft_size;
     const dim3 grid((unsigned)((fft_size + 255) / 256), g);
     hipLaunchKernelGGL(al::k_stft_pack, grid, dim3(256), 0, st, y, n, n_frames, fft_size, win_size, hop_size, s0, a);
-    const float2 *z = big_fft(a, b, g, fft_size, -1, st);
+    const float2 *z = any_fft(a, b, tmp, g, fft_size, -1, st);
     hipLaunchKernelGGL(al::k_stft_take_half, grid, dim3(256), 0, st, z, fft_size, s0, reinterpret_cast<float2 *>(spec));
   }
   return check_launch("al_stft");
@@ -1809,7 +1838,8 @@ int al_tv_stft_mac(const float *s_audio, const float *s_ir, const float *w_ir, i
 
 int64_t al_istft_workspace_floats(int32_t n_frames, int32_t n_ch, int32_t fft_size) {
   if (n_frames <= 0 || n_ch <= 0 || fft_size <= 0) return 0;
-  return 2 * 2 * (int64_t)n_frames * n_ch * fft_size;
+  const int64_t series = (int64_t)n_frames * n_ch;
+  return 2 * 2 * series * fft_size + any_fft_tmp_floats(series < MAX_GRID_ROWS ? series : MAX_GRID_ROWS, fft_size);
 }
 
 int al_istft_ola(const float *spatial_stft, int32_t n_frames, int32_t n_freq, int32_t n_ch, int32_t fft_size,
@@ -1817,19 +1847,19 @@ int al_istft_ola(const float *spatial_stft, int32_t n_frames, int32_t n_freq, in
   if (!spatial_stft || !out || !workspace || n_frames <= 0 || n_ch <= 0 || fft_size <= 0 || win_size <= 0 || hop_size <= 0)
     return fail(AL_E_BADARG, "bad istft arguments");
   if (n_freq != fft_size / 2 + 1) return fail(AL_E_BADARG, "istft: n_freq must be fft_size / 2 + 1");
-  if (!smooth_length(fft_size)) return fail(AL_E_UNSUPPORTED, "istft: fft_size must factor into 2, 3, 5, 7");
   if ((int64_t)n_frames * hop_size <= win_size) return fail(AL_E_BADARG, "istft: no output samples");
   hipStream_t st = (hipStream_t)stream;
   const int64_t series = (int64_t)n_frames * n_ch;
   float2 *a = reinterpret_cast<float2 *>(workspace), *b = a + series * fft_size;
+  float *tmp = reinterpret_cast<float *>(b + series * fft_size);
   const float2 *frames = nullptr;
   for (int64_t s0 = 0; s0 < series; s0 += MAX_GRID_ROWS) {
     const int g = (int)(series - s0 < MAX_GRID_ROWS ? series - s0 : MAX_GRID_ROWS);
     const dim3 grid((unsigned)((fft_size + 255) / 256), g);
     hipLaunchKernelGGL(al::k_istft_pack, grid, dim3(256), 0, st, reinterpret_cast<const float2 *>(spatial_stft), n_freq, n_ch,
                        fft_size, s0, a + s0 * fft_size);
-    const float2 *z = big_fft(a + s0 * fft_size, b + s0 * fft_size, g, fft_size, +1, st);
-    frames = (z == a + s0 * fft_size) ? a : b;  // every group ends in the same buffer (same pass count)
+    const float2 *z = any_fft(a + s0 * fft_size, b + s0 * fft_size, tmp, g, fft_size, +1, st);
+    frames = (z == a + s0 * fft_size) ? a : b;  // every group ends in the same buffer (same pass count; Bluestein: always the second)
   }
   const int64_t total = ((int64_t)n_frames * hop_size - win_size) * n_ch;
   hipLaunchKernelGGL(al::k_istft_ola, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, frames, n_frames, n_ch, fft_size,

@@ -94,19 +94,6 @@ def _check_geometry(fft_size: int, win_size: int, hop_size: int) -> None:
                          f"overlap-add buffer, fft_size must be at most 2*hop_size + win_size = {2 * hop_size + win_size}")
 
 
-def _check_general_geometry(fft_size: int, n_audio: int, hop_size: int) -> None:
-    """What the literal STFT chain of THIS build cannot transform, said before anything is uploaded (the reference renders these;
-    here they would surface as a HipError from inside the chain): al_stft / al_istft_ola take fft sizes that factor into 2, 3, 5
-    and 7 (the mixed-radix passes of csrc/al_bigfft.h)."""
-    m = int(fft_size)
-    for p in (2, 3, 5, 7):
-        while m % p == 0:
-            m //= p
-    if m != 1:
-        raise ValueError(f"fft_size = {fft_size} is not supported by this build for STFT geometries outside win = 2 * hop, fft >= 2 * win - 1: "
-                         f"it must factor into 2, 3, 5 and 7 (largest other factor: {m})")
-
-
 def _permuted(buf, shape, axes):
     """A contiguous device copy of ``buf`` viewed as ``shape`` with its axes permuted (a copy, no arithmetic)."""
     n = int(np.prod(shape))
@@ -172,7 +159,6 @@ def time_variant_convolution(irs: np.ndarray, event, fft_size=config.FFT_SIZE, w
     _check_geometry(fft_size, win_size, hop_size)
     n_ch, n_irs, n_ir = irs.shape
     if not _envelope_geometry(fft_size, win_size, hop_size):
-        _check_general_geometry(fft_size, len(audio), hop_size)
         r = get_renderer()
         ir_dev = r.mem.upload(np.ascontiguousarray(irs, dtype=np.float32).reshape(-1))
         out, n_out = _tv_chain_on_device(r, ir_dev, n_ch, n_irs, n_ir, r.mem.upload(np.ascontiguousarray(audio)), len(audio),
@@ -514,7 +500,6 @@ def render_event_audio(event, irs: np.ndarray, mic_alias: str, ref_db=config.DEF
     if n_emitters > 1:
         _check_geometry(fft_size, win_size, hop_size)
     if n_emitters > 1 and not _envelope_geometry(fft_size, win_size, hop_size):
-        _check_general_geometry(fft_size, len(clip), hop_size)
         res = _render_moving_general(r, spec, clip, irs, fft_size, win_size, hop_size, float(event.sample_rate))
     else:
         geometry = dict(hop=hop_size, win=win_size, fft_size=fft_size) if n_emitters > 1 else {}   # static / tiled events never frame

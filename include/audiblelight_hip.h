@@ -312,7 +312,8 @@ int al_scale_matrix_rows(float *x, int32_t rows, int64_t cols, const float *scal
 /* ---- STFT-domain intermediates of the moving-source path (A7).  The render path evaluates the same result in the
  * envelope form (al_signal_spectra / al_spectral_mac); these three give the reference's public helper functions of the
  * same names a device implementation with the reference's array layouts (C order, complex64 as interleaved floats).
- * fft_size must factor into 2, 3, 5, 7. */
+ * Any fft_size: Stockham passes of radix 2 / 3 / 4 / 5 / 7 where it factors into those, Bluestein's chirp-z on a power-of-two length
+ * otherwise (numpy's rfft / irfft in the reference take any size, synthesize.py:135,263); the workspace functions account for it. */
 /* stft (synthesize.py:109-145): y (rows, n) float32 -> spec (rows, n_frames, fft_size/2+1) complex64,
  * n_frames = 2*ceil(n / (2*hop)) + 1, window sin^2(pi t / win), left pad win-hop, rfft norm="backward". */
 int64_t al_stft_workspace_floats(int64_t series /* rows * n_frames */, int32_t fft_size);

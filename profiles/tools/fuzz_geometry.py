@@ -1,5 +1,5 @@
 """Lease-side evidence beside test_moving_events_under_other_stft_geometries: random STFT geometries (any the reference accepts:
-win >= hop, fft <= 2*hop + win, fft_size a product of 2, 3, 5, 7) x random moving events through render_event_audio on the MI355X,
+win >= hop, fft <= 2*hop + win; fft_size a product of 2, 3, 5, 7 on even seeds, ANY integer on odd ones: Bluestein) x random moving events through render_event_audio on the MI355X,
 every row against the oracle's literal STFT-domain restatement (pinned to the reference on seven geometries, G14).
     python3 profiles/tools/fuzz_geometry.py FIRST LAST"""
 import os
@@ -24,6 +24,8 @@ def case(seed):
     win = int(rng.integers(hop, 4 * hop + 1))
     ok = [f for f in SMOOTH if f <= 2 * hop + win]
     fft = int(rng.choice(ok[-12:])) if rng.random() < 0.7 else int(rng.choice(ok))     # mostly near the upper limit, some far below win
+    if seed % 2:      # any size at all (primes included): al_stft / al_istft_ola through Bluestein's chirp-z
+        fft = int(np.random.default_rng(86_000 + seed).integers(max(32, (2 * hop + win) // 3), min(1024, 2 * hop + win) + 1))
     n_irs, C = int(rng.integers(2, 7)), int(rng.integers(1, 5))
     La, Lir, sr = int(rng.integers(2000, 12000)), int(rng.integers(300, 3000)), int(rng.choice([8000, 16000, 44100]))
     a = rng.standard_normal(La).astype(np.float32)

@@ -119,13 +119,16 @@ SMOOTH = sorted({2 ** a * 3 ** b * 5 ** c * 7 ** d for a in range(11) for b in r
 
 
 def geometry_case(seed, ref_syn, ours):
-    """One moving event under a random STFT geometry the reference accepts (win >= hop, fft <= 2*hop + win; fft a product of 2, 3, 5, 7:
-    this package's own limit), rendered by the reference's render_event_audio and by ours (synthesize.py:507-608,277-310)."""
+    """One moving event under a random STFT geometry the reference accepts (win >= hop, fft <= 2*hop + win; ANY fft size -- half the
+    seeds draw a product of 2, 3, 5, 7, the other half any integer, primes included: Bluestein), rendered by the reference's
+    render_event_audio and by ours (synthesize.py:507-608,277-310)."""
     rng = np.random.default_rng(85_000 + seed)
     hop = int(rng.integers(16, 200))
     win = int(rng.integers(hop, 3 * hop + 1))
     ok = [f for f in SMOOTH if f <= 2 * hop + win]
     fft = int(rng.choice(ok[-10:])) if rng.random() < 0.7 else int(rng.choice(ok))
+    if seed % 2:                                                    # any size at all (a generator of its own: the other draws stay)
+        fft = int(np.random.default_rng(86_000 + seed).integers(max(32, (2 * hop + win) // 3), min(1024, 2 * hop + win) + 1))
     n_irs, n_caps, sr = int(rng.integers(2, 6)), int(rng.integers(1, 4)), 8000
     a, h = mg.make_clip(rng, int(rng.integers(1500, 6000))), mg.make_irs(rng, n_caps, n_irs, int(rng.integers(100, 1200)))
     snr = float(rng.uniform(5, 30))

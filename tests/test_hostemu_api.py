@@ -402,8 +402,12 @@ def test_stft_helpers_match_reference():
     tv = syn.time_variant_convolution(h.astype(np.float64), ev)
     chain = syn.istft_overlap_synthesis(syn.perform_time_variant_convolution(s_a, s_h, z["g10_w"])).T
     assert_parity(tv[:, : chain.shape[1]], chain[:, : tv.shape[1]], TOL)
-    with pytest.raises(Exception, match="fft_size must factor"):
-        syn.stft(a, 2 * 11 * 13, 256, 128)
+    # an fft size with prime factors above 7 goes through Bluestein's chirp-z (it was refused until round 6): against numpy's rfft
+    big = syn.stft(a, 2 * 11 * 13, 256, 128)
+    ref = orc.stft_frames(a.astype(np.float64), 2 * 11 * 13, 256, 128)
+    assert big.shape == ref.shape
+    assert_parity(big.real, ref.real, 1e-5, what="stft 286 re")
+    assert_parity(big.imag, ref.imag, 1e-5, what="stft 286 im")
 
 
 def test_moving_events_under_other_stft_geometries():
@@ -468,10 +472,12 @@ def test_moving_events_under_other_stft_geometries():
 
 
 def test_general_stft_path_limits():
-    """Advisor r05: the literal STFT chain behind non-default geometries.  More output frames than one launch's grid holds
-    (hop 16 at 44.1 kHz passes 65 535 frames after 23 s of clip): al_tv_stft_mac walks the frame axis in groups -- 70 000 frames here
-    against the defining sum (synthesize.py:217-250).  An fft size the mixed-radix transforms of this build do not take is refused
-    with a ValueError that names it BEFORE anything is uploaded, from render_event_audio and from time_variant_convolution alike."""
+    """Advisor r05: the literal STFT chain behind non-default geometries has no limits of its own left.  More output frames than one
+    launch's grid holds (hop 16 at 44.1 kHz passes 65 535 frames after 23 s of clip): al_tv_stft_mac walks the frame axis in groups --
+    70 000 frames here against the defining sum (synthesize.py:217-250).  An fft size with a prime factor above 7 (the reference's
+    numpy rfft / irfft take any size, synthesize.py:135,263): al_stft / al_istft_ola go through Bluestein's chirp-z -- fft sizes 22
+    (2 x 11), 23 (prime, odd) and 26 (2 x 13) against the oracle's literal STFT-domain restatement, every row, through
+    render_event_audio and time_variant_convolution alike."""
     rng = np.random.default_rng(5)
     n_frames, f_ir, n_freq, n_ch, n_irs = 70_000, 2, 2, 1, 2
     s_a = (rng.standard_normal((n_frames, n_freq)) + 1j * rng.standard_normal((n_frames, n_freq))).astype(np.complex64)
@@ -488,16 +494,23 @@ def test_general_stft_path_limits():
 
     a = rng.standard_normal(3000).astype(np.float32)
     a /= np.abs(a).max()
-    h = rng.standard_normal((2, 3, 200)).astype(np.float32)
-    ev = types.SimpleNamespace(alias="m", snr=7.0, sample_rate=8000, is_moving=True, duration=3000 / 8000, spatial_audio={},
-                               _spatial_audio_dry={}, ref_ir_channel=None, direct_path_time_ms=None,
-                               load_audio=lambda ignore_cache=False, normalize=True: a, __len__=lambda: 3)
-    for call in (lambda: syn.render_event_audio(ev, h, "m", fft_size=22, win_size=12, hop_size=5),
-                 lambda: syn.time_variant_convolution(h, ev, fft_size=22, win_size=12, hop_size=5)):
-        with pytest.raises(ValueError, match="fft_size = 22 is not supported by this build.*largest other factor: 11"):
-            call()
-    syn.render_event_audio(ev, h, "m", fft_size=20, win_size=12, hop_size=5)      # 20 = 2^2 * 5: the same geometry class renders
-    assert np.isfinite(ev.spatial_audio["m"]).all() and ev.spatial_audio["m"].shape == (2, 3000)
+    h = (rng.standard_normal((2, 3, 200)) * np.exp(-np.arange(200) / 40.0)).astype(np.float32)
+    for fft, win, hop in ((22, 12, 5), (23, 12, 6), (26, 13, 7)):
+        ev = types.SimpleNamespace(alias="m", snr=7.0, sample_rate=8000, is_moving=True, duration=3000 / 8000, spatial_audio={},
+                                   _spatial_audio_dry={}, ref_ir_channel=None, direct_path_time_ms=None,
+                                   load_audio=lambda ignore_cache=False, normalize=True: a, __len__=lambda: 3)
+        syn.render_event_audio(ev, h, "m", ref_db=-60, fft_size=fft, win_size=win, hop_size=hop)
+        want = orc.render_event(a, h.astype(np.float64), 7.0, ref_db=-60, is_moving=True, duration=3000 / 8000, sr=8000, nfft=fft, win=win,
+                                hop=hop)["spatial"]
+        assert_parity(ev.spatial_audio["m"], want, TOL, what=(fft, win, hop))
+        raw = syn.time_variant_convolution(h, ev, fft_size=fft, win_size=win, hop_size=hop)
+        assert_parity(raw, orc.convolve_moving_stft(a, h.astype(np.float64), 3000 / 8000, 8000, fft, win, hop), TOL, what=("raw", fft))
+    # the forward helper itself at a prime size, against the oracle's frames (numpy rfft)
+    y = rng.standard_normal((2, 500)).astype(np.float32)
+    spec, ref = syn.stft(y, fft_size=23, win_size=12, hop_size=6), orc.stft_frames(y.astype(np.float64), 23, 12, 6)
+    assert spec.shape == ref.shape
+    assert_parity(spec.real, ref.real, 1e-5, what="stft 23 re")
+    assert_parity(spec.imag, ref.imag, 1e-5, what="stft 23 im")
 
 
 def test_degenerate_events_render_like_the_reference():

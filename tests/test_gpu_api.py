@@ -120,3 +120,29 @@ def test_free_bytes_reads_the_allocator_counters(gpu_renderer):
     free, _ = torch.cuda.mem_get_info()
     want = free + torch.cuda.memory_reserved() - torch.cuda.memory_allocated()
     assert gpu_renderer.mem.free_bytes() == want and torch.cuda.memory_reserved() > torch.cuda.memory_allocated()
+
+
+def test_general_stft_path_beyond_one_grid_of_frames():
+    """A clip of 70 001 STFT frames (hop 2: more than the 65 535 rows one launch's grid holds; hop 16 at 44.1 kHz gets there after
+    23 s) through render_event_audio's literal STFT chain -- al_stft, al_tv_stft_mac and al_istft_ola all walk their frame axes in
+    groups of launches -- against the oracle's literal restatement (synthesize.py:184-310), every sample.  (GPU only: the host
+    emulation needs 90 s for it.)"""
+    import types
+
+    import numpy as np
+
+    from audiblelight_amd import synthesize as syn
+    from oracle import synth_oracle as orc
+    from tests.conftest import assert_parity
+
+    rng = np.random.default_rng(1)
+    n = 140_001
+    a = rng.standard_normal(n).astype(np.float32)
+    a /= np.abs(a).max()
+    h = rng.standard_normal((2, 2, 20)).astype(np.float32)
+    ev = types.SimpleNamespace(alias="m", snr=7.0, sample_rate=8000, is_moving=True, duration=n / 8000, spatial_audio={},
+                               _spatial_audio_dry={}, ref_ir_channel=None, direct_path_time_ms=None,
+                               load_audio=lambda ignore_cache=False, normalize=True: a, __len__=lambda: 2)
+    syn.render_event_audio(ev, h, "m", ref_db=-60, fft_size=6, win_size=3, hop_size=2)
+    want = orc.render_event(a, h.astype(np.float64), 7.0, ref_db=-60, is_moving=True, duration=n / 8000, sr=8000, nfft=6, win=3, hop=2)
+    assert_parity(ev.spatial_audio["m"], want["spatial"], 1e-4, what="70 001 frames")

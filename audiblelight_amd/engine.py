@@ -533,7 +533,9 @@ class Renderer:
             for desc in descs:
                 self.lib.call("al_clip_scales", ct.byref(desc), mem.ptr(pre), mem.ptr(mode), mem.stream())
             bufs["_clip_tables"] = (pre, mode)
-        return PreparedBatch(self, plan, bufs, descs, lanes)
+        batch = PreparedBatch(self, plan, bufs, descs, lanes)
+        batch.energy_only = not spectra_workspaces
+        return batch
 
     def _forced_dispatch(self, desc, plan: BatchPlan, sw) -> int:
         """al_batch.flags with the A/B switches applied on top of the library's policy (tests and measurements only)."""
@@ -629,7 +631,17 @@ class PreparedBatch:
             cur.wait_stream(st)
         return self.result()
 
+    ENERGY_ONLY_STAGES = ("al_ir_spectra", "al_emitter_gains", "al_emitter_norm_sums", "al_emitter_gains_from_sums", "al_event_levels_from_stats")
+    energy_only = False      # prepare(spectra_workspaces=False): the H / X / Y workspaces are one block each
+
+    def _check_stage(self, name: str) -> None:
+        if self.energy_only and name not in self.ENERGY_ONLY_STAGES:
+            raise RuntimeError(f"{name}: this batch was prepared without spectra workspaces (spectra_workspaces=False): only the IR "
+                               f"energy pass and the level law may run on it")
+
     def run(self, stages: Optional[Sequence[str]] = None) -> RenderResult:
+        for name in (self.STAGES if stages is None else stages):
+            self._check_stage(name)
         if self.lanes > 1 and stages is None and hasattr(self.renderer.mem, "torch"):
             return self._run_lanes()
         lib, stream = self.renderer.lib, self.renderer.mem.stream()
@@ -643,6 +655,7 @@ class PreparedBatch:
         return self.STAGES
 
     def run_stage(self, name: str, chunk: int = 0) -> None:
+        self._check_stage(name)
         self.renderer.lib.call(name, ct.byref(self.descs[chunk]), self.renderer.mem.stream())
 
     def result(self) -> RenderResult:

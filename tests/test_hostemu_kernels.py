@@ -157,3 +157,22 @@ def test_emu_full_scene_with_ambience(emu, golden):
     scene2 = emu.mem.download(emu.mixdown(mix, res))[: C * mix.n_samples].reshape(C, mix.n_samples)
     want = golden["g8_scene"].astype(np.float64) - mult * amb.astype(np.float64)
     assert rel_rms(scene2, want) < 2e-4
+
+
+def test_energy_only_batches_refuse_the_spectra_stages(emu):
+    """Renderer.prepare(spectra_workspaces=False) -- the general STFT path's batch: IR energy pass + level law only -- allocates one
+    block per spectra workspace; running a transform / accumulate stage on it would write far past them, so the batch refuses."""
+    rng = np.random.default_rng(3)
+    a = rng.standard_normal(5000).astype(np.float32)
+    h = rng.standard_normal((2, 3, 700)).astype(np.float32)
+    spec = planning.EventSpec(n_samples=len(a), n_emitters=3, snr=5.0, is_moving=True, duration=len(a) / 8000)
+    pl = planning.plan_batch([spec], 2, 700, 8000, log2_block=10)
+    batch = emu.prepare(pl, [a], h, emitter_parts=np.zeros(3, dtype=np.int32), spectra_workspaces=False)
+    assert batch.energy_only and len(batch.bufs["yspec"]) <= 2 * 2 * 1024 + 16
+    batch.run_stage("al_ir_spectra")
+    batch.run_stage("al_emitter_gains")
+    gains = np.asarray(emu.mem.download(batch.bufs["emitter_gain"]))[:3]
+    np.testing.assert_allclose(gains, orc.emitter_gains(h), rtol=2e-5)
+    for call in (lambda: batch.run(), lambda: batch.run_stage("al_spectral_mac"), lambda: batch.run(stages=("al_block_synthesis",))):
+        with pytest.raises(RuntimeError, match="without spectra workspaces"):
+            call()

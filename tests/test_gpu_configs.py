@@ -388,6 +388,14 @@ def test_bench_collectives_on_rccl_with_one_rank():
     assert out["n_gpus"] == 1 and out["gather"]["backend"] == "nccl" and out["gather"]["bytes_total"] == 4 * 4 * 240000
     assert out["data"] == "synthetic" and out["value"] > 0 and out["gather"]["ranks_seen"] == [0]
     assert out["timing"]["repeats"] == 3 and out["steps"] == 20
+    assert out["gather"]["xgmi_link_peak_GBps"] == 153.0 and out["gather"]["render_ms"] == out["ms_per_step"]
+    # the PCIe-inclusive legs as a multi-rank run makes them: behind RCCL barriers, pass times reduced with MAX over the ranks
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "5", "--repeats", "1", "--cpu-events", "0",
+                          "--cpu-workers", "0", "--end-to-end", "4", "--dropin", "2"], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    legs = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert legs["end_to_end"]["value"] > 0 and legs["end_to_end"]["scenes"] == 4 and len(legs["end_to_end"]["passes"]) == 3
+    assert legs["end_to_end_dropin"]["value"] > 0 and legs["end_to_end_dropin"]["scenes"] == 2
     # the other two modes on the same backend: a batch of scenes all gathered, one scene with its capsules "sharded" over one rank
     common = [sys.executable, os.path.join(root, "bench.py"), "--config", "cfg1", "--steps", "5", "--repeats", "1", "--cpu-events", "0",
               "--cpu-workers", "0"]

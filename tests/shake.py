@@ -22,6 +22,13 @@ VARIANTS = {
     "s3w": ["-DAL_SHAKE=3", "-DAL_Q16_WAVES=1", "-DAL_SPLIT_WAVES=2"],
     "revert": ["-DAL_SHAKE=3", "-DAL_TEST_REVERT_Q16_BARRIER=1"],
 }
+# further skews, built on demand only (profiles/tools/shake_diag.py s2 s4 s5 s6: a wider sweep than the test suite's two variants)
+EXTRA_VARIANTS = {
+    "s2": ["-DAL_SHAKE=2"],
+    "s4": ["-DAL_SHAKE=4"],                      # wave 0 always the FIRST to move on
+    "s5": ["-DAL_SHAKE=5", "-DAL_Q16_WAVES=1"],
+    "s6": ["-DAL_SHAKE=6", "-DAL_SPLIT_WAVES=2"],
+}
 
 
 def library_path(name: str) -> str:
@@ -47,7 +54,7 @@ def build(names=None) -> dict:
         objs = []
         for src, extra in (("al_kernels.hip", []), ("al_transforms.hip", ["-fno-slp-vectorize"])):
             obj = os.path.join(OUT, f"{os.path.splitext(src)[0]}_{name}.o")
-            jobs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + extra + VARIANTS[name]
+            jobs.append(subprocess.Popen([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c"] + extra + {**VARIANTS, **EXTRA_VARIANTS}[name]
                                          + [os.path.join(CSRC, src), "-o", obj]))
             objs.append(obj)
         todo.append((name, objs))
